@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU oracle (libabr_oracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  Nothing under abrsimulator_amd/ may.
+
+Parity status: pinned (see abr_oracle.c header and tests/test_oracle_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [("n_rates", C.c_int32), ("video_length", C.c_int32),
+                ("chunk_length", C.c_double), ("max_buffer", C.c_double),
+                ("start_up_length", C.c_double), ("interval", C.c_double),
+                ("rebuffer_weight", C.c_double), ("variance_weight", C.c_double),
+                ("startup_weight", C.c_double), ("latency_weight", C.c_double),
+                ("speed", C.c_double), ("ladder", C.c_double * 16)]
+
+
+class MpcCfg(C.Structure):
+    _fields_ = [("n_rates", C.c_int32), ("horizon", C.c_int32), ("video_length", C.c_int32),
+                ("_pad", C.c_int32), ("chunk_length", C.c_double), ("max_buffer", C.c_double),
+                ("variance_weight", C.c_double), ("rebuffer_weight", C.c_double),
+                ("startup_weight", C.c_double)]
+
+
+STEP_DTYPE = np.dtype([
+    ("global_time", "f8"), ("rebuffer_time", "f8"), ("start_up_time", "f8"), ("play_time", "f8"),
+    ("average_latency", "f8"), ("buffer_level", "f8"), ("play_length", "f8"),
+    ("instant_latency", "f8"), ("last_bandwidth", "f8"),
+    ("chunk_id", "i4"), ("play_id", "i4"), ("last_bitrate", "i4"),
+    ("start_up", "i4"), ("buffer_empty", "i4"), ("buffer_full", "i4")], align=True)
+
+FINAL_DTYPE = np.dtype([
+    ("qoe", "f8"), ("rebuffer_time", "f8"), ("start_up_time", "f8"), ("average_latency", "f8"),
+    ("global_time", "f8"), ("buffer_level", "f8"), ("play_time", "f8"),
+    ("ticks", "i8"), ("play_id", "i4"), ("chunk_id", "i4")], align=True)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libabr_oracle.so")
+    src = os.path.join(_HERE, "abr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libabr_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_env_batch.restype = C.c_int64
+        _LIB.oracle_mpc_brute.restype = C.c_int64
+        _LIB.oracle_mpc_objective.restype = C.c_double
+        assert STEP_DTYPE.itemsize == 96 and FINAL_DTYPE.itemsize == 72
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def env_cfg(ladder, chunk_length, video_length, max_buffer, start_up_length, interval,
+            weights, speed=1.0):
+    c = EnvCfg()
+    c.n_rates, c.video_length = len(ladder), int(video_length)
+    c.chunk_length, c.max_buffer = float(chunk_length), float(max_buffer)
+    c.start_up_length, c.interval = float(start_up_length), float(interval)
+    (c.rebuffer_weight, c.variance_weight, c.startup_weight, c.latency_weight) = map(float, weights)
+    c.speed = float(speed)
+    for i, b in enumerate(ladder):
+        c.ladder[i] = float(b)
+    return c
+
+
+def pack_traces(traces):
+    """list of 1-D arrays (ragged ok) -> (flat f8, off i8, len i4)."""
+    lens = np.array([len(t) for t in traces], np.int32)
+    off = np.zeros(len(traces), np.int64)
+    off[1:] = np.cumsum(lens[:-1])
+    flat = np.concatenate([np.asarray(t, np.float64) for t in traces])
+    return np.ascontiguousarray(flat), off, lens
+
+
+def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40):
+    """Replay episodes. traces: list of arrays. actions: [N, V] int32.
+    Returns (steps[N,V] STEP_DTYPE, bw[N,V], final[N] FINAL_DTYPE, total_ticks)."""
+    flat, off, lens = pack_traces(traces)
+    trace_id = np.ascontiguousarray(trace_id, np.int32)
+    offset = np.ascontiguousarray(offset, np.int32)
+    actions = np.ascontiguousarray(actions, np.int32)
+    N, V = actions.shape
+    assert V == cfg.video_length
+    steps = np.zeros((N, V), STEP_DTYPE)
+    bw = np.zeros((N, V), np.float64)
+    fin = np.zeros(N, FINAL_DTYPE)
+    rc = lib().oracle_env_batch(
+        C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
+        _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32), C.c_int32(N),
+        steps.ctypes.data_as(C.c_void_p), _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p),
+        C.c_int64(max_ticks))
+    if rc < 0:
+        raise RuntimeError(f"oracle_env_batch failed: {rc}")
+    return steps, bw, fin, int(rc)
+
+
+POLICY_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+
+def env_episode_policy(cfg, trace, offset, policy, max_ticks=1 << 40):
+    """One episode driven by a Python callback policy(obs_record, prev_bw_array) -> int."""
+    trace = np.ascontiguousarray(trace, np.float64)
+    V = cfg.video_length
+    steps = np.zeros(V, STEP_DTYPE)
+    bw = np.zeros(V, np.float64)
+    acts = np.zeros(V, np.int32)
+    fin = np.zeros(1, FINAL_DTYPE)
+
+    def cb(_ctx, obs_ptr, bw_ptr, n):
+        obs = np.frombuffer((C.c_char * STEP_DTYPE.itemsize).from_address(obs_ptr),
+                            dtype=STEP_DTYPE, count=1)[0]
+        hist = np.ctypeslib.as_array(bw_ptr, shape=(n,)).copy() if n else np.zeros(0)
+        return int(policy(obs, hist))
+
+    rc = lib().oracle_env_episode(
+        C.byref(cfg), _p(trace, C.c_double), C.c_int32(len(trace)), C.c_int32(int(offset)),
+        None, POLICY_FN(cb), None, steps.ctypes.data_as(C.c_void_p), _p(bw, C.c_double),
+        _p(acts, C.c_int32), fin.ctypes.data_as(C.c_void_p), C.c_int64(max_ticks))
+    if rc:
+        raise RuntimeError(f"oracle_env_episode failed: {rc}")
+    return steps, bw, acts, fin[0]
+
+
+def mpc_cfg(n_rates, horizon, video_length, chunk_length, max_buffer, variance_weight,
+            rebuffer_weight, startup_weight=0.0):
+    c = MpcCfg()
+    c.n_rates, c.horizon, c.video_length = int(n_rates), int(horizon), int(video_length)
+    c.chunk_length, c.max_buffer = float(chunk_length), float(max_buffer)
+    c.variance_weight, c.rebuffer_weight = float(variance_weight), float(rebuffer_weight)
+    c.startup_weight = float(startup_weight)
+    return c
+
+
+def mpc_predict_list(horizon, hist):
+    """Returns (pred[H], mutated history list) -- mpc.py:81-93 literal."""
+    h = np.zeros(len(hist) + horizon, np.float64)
+    h[:len(hist)] = hist
+    n = C.c_int32(len(hist))
+    pred = np.zeros(horizon, np.float64)
+    lib().oracle_mpc_predict_list(C.c_int32(horizon), _p(h, C.c_double), C.byref(n),
+                                  _p(pred, C.c_double))
+    return pred, h[:n.value]
+
+
+def mpc_brute(cfg, br, sz, chunk, prev, buf, pred, want_J=True):
+    br = np.ascontiguousarray(br, np.float64)
+    sz = np.ascontiguousarray(sz, np.float64)
+    pred = np.ascontiguousarray(pred, np.float64)
+    J = np.zeros(cfg.n_rates ** cfg.horizon, np.float64) if want_J else None
+    Jmin = C.c_double()
+    flat = lib().oracle_mpc_brute(C.byref(cfg), _p(br, C.c_double), _p(sz, C.c_double),
+                                  C.c_int(int(chunk)), C.c_int(int(prev)), C.c_double(float(buf)),
+                                  _p(pred, C.c_double), _p(J, C.c_double), C.byref(Jmin))
+    return int(flat), Jmin.value, J
+
+
+def mpc_select(cfg, br, sz, chunk, prev, buf, hist_n, hist_s):
+    """Batched next_bitrate. hist_n/hist_s are updated IN PLACE (D9).
+    Returns (action i4[N], flat i8[N], Jmin f8[N], pred f8[N,H])."""
+    br = np.ascontiguousarray(br, np.float64)
+    sz = np.ascontiguousarray(sz, np.float64)
+    chunk = np.ascontiguousarray(chunk, np.int32)
+    prev = np.ascontiguousarray(prev, np.int32)
+    buf = np.ascontiguousarray(buf, np.float64)
+    assert hist_n.dtype == np.float64 and hist_s.dtype == np.float64
+    N = len(chunk)
+    act = np.zeros(N, np.int32)
+    flat = np.zeros(N, np.int64)
+    Jm = np.zeros(N, np.float64)
+    pred = np.zeros((N, cfg.horizon), np.float64)
+    rc = lib().oracle_mpc_select(C.byref(cfg), _p(br, C.c_double), _p(sz, C.c_double),
+                                 _p(chunk, C.c_int32), _p(prev, C.c_int32), _p(buf, C.c_double),
+                                 _p(hist_n, C.c_double), _p(hist_s, C.c_double), C.c_int32(N),
+                                 _p(act, C.c_int32), _p(flat, C.c_int64), _p(Jm, C.c_double),
+                                 _p(pred, C.c_double))
+    if rc:
+        raise RuntimeError(f"oracle_mpc_select failed: {rc}")
+    return act, flat, Jm, pred

@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+This script is the only place in the repository that touches /root/reference.
+It runs in the build container only (the reference never travels to the GPU
+box); its outputs -- small .npz/.json files holding inputs and expected
+outputs, no reference source -- are committed under tests/golden/.
+
+What it runs
+------------
+* mpc.py, imported as-is with an empty `statsmodels` stub registered in
+  sys.modules (mpc.py:4 hard-imports an absent package; only the unused
+  `expsmoothing` branch mpc.py:72-79 needs it).
+* Simulator.py, read as text and exec'd IN MEMORY after the three control-flow
+  repairs SURVEY.md section 8(c) enumerates (no arithmetic line is touched):
+    R1  Simulator.py:210  the `return` is dedented out of the while body
+    R2  Simulator.py:144-145  `else: download_pause = False`
+    R3  Simulator.py:148-149  `else: play_pause = False`
+  The repaired module is never written to disk.
+
+Per-step goldens are captured inside the ABR callback (Simulator.py:155):
+its four arguments plus the `run()` frame locals at that instant.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "tests", "golden")
+
+
+# --------------------------------------------------------------------------
+# loading the reference
+# --------------------------------------------------------------------------
+def load_mpc():
+    for n in ("statsmodels", "statsmodels.tsa", "statsmodels.tsa.holtwinters"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules["statsmodels.tsa.holtwinters"].SimpleExpSmoothing = None
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import mpc  # noqa: E402
+    return mpc
+
+
+def load_simulator_repaired():
+    with open(os.path.join(REF, "Simulator.py")) as f:
+        lines = f.read().split("\n")
+    # line numbers are 1-based in the citations; list is 0-based
+    assert lines[209].strip().startswith("return self.calculate_qoe"), lines[209]
+    assert lines[144].strip() == "download_pause = True", lines[144]
+    assert lines[148].strip() == "play_pause = True", lines[148]
+    # R1: dedent the return by one level (out of the while body)
+    lines[209] = lines[209][4:]
+    # R3 first (so R2's insert does not shift it): else after line 149
+    ind_if = len(lines[147]) - len(lines[147].lstrip())
+    lines.insert(149, " " * ind_if + "else:\n" + " " * (ind_if + 4) + "play_pause = False")
+    ind_if = len(lines[143]) - len(lines[143].lstrip())
+    lines.insert(145, " " * ind_if + "else:\n" + " " * (ind_if + 4) + "download_pause = False")
+    mod = types.ModuleType("Simulator_repaired_in_memory")
+    exec(compile("\n".join(lines), "<Simulator.py + R1-R3>", "exec"), mod.__dict__)
+    return mod
+
+
+# --------------------------------------------------------------------------
+# env goldens
+# --------------------------------------------------------------------------
+STEP_F64 = ["global_time", "rebuffer_time", "start_up_time", "play_time",
+            "average_latency", "buffer_level", "play_length", "instant_latency"]
+STEP_I32 = ["chunk_id", "play_id", "start_up", "buffer_empty", "buffer_full"]
+
+
+class RecordingAbr:
+    """ABR plugin handed to the reference Simulator: replays a fixed action
+    list and snapshots the caller's frame (Simulator.run locals)."""
+
+    def __init__(self, actions):
+        self.actions = actions
+        self.rec = []
+
+    def get_next_bitrate(self, chunk_id, previous_bitrates, previous_bandwidths, buffer_level):
+        loc = sys._getframe(1).f_locals
+        r = {k: float(loc[k]) for k in STEP_F64}
+        r.update({k: int(loc[k]) for k in STEP_I32})
+        assert r["chunk_id"] == chunk_id and r["buffer_level"] == float(buffer_level)
+        r["arg_last_bitrate"] = previous_bitrates[-1] if previous_bitrates else -1
+        r["arg_last_bandwidth"] = previous_bandwidths[-1] if previous_bandwidths else 0.0
+        r["arg_hist_len"] = len(previous_bandwidths)
+        self.rec.append(r)
+        return self.actions[chunk_id]
+
+
+class ConstSpeed:
+    def __init__(self, s):
+        self.s = s
+
+    def get_next_speed(self):
+        return self.s
+
+
+def run_lane(S, cfg, trace, actions, tmpdir):
+    """One reference episode. Returns (per-step records, final dict)."""
+    abr = RecordingAbr(actions)
+    sim = S.Simulator(abr, ConstSpeed(cfg["speed"]))
+    sim.set_qoe_metric(S.QOEMetric(*cfg["weights"]))
+    # trace goes through the reference's own loader (Simulator.py:59-65)
+    path = os.path.join(tmpdir, "trace.txt")
+    with open(path, "w") as f:
+        for v in trace:
+            f.write(repr(float(v)) + "\n")
+    sim.set_network_info(cfg["interval"], path)
+    assert sim.network_info.bandwidths == [float(v) for v in trace]
+    # D4: set_mpd's parser raises TypeError; build the MPD directly with the
+    # single-ladder Chunk that run()/calculate_qoe index (Simulator.py:82,156)
+    sim.mpd = S.MPD(cfg["video_length"], cfg["chunk_length"], cfg["max_buffer"],
+                    cfg["start_up_length"], S.Chunk(list(cfg["ladder"])))
+    final = {}
+    orig = sim.calculate_qoe
+
+    def spy(rebuffer_time, previous_bitrates, start_up_time, average_latency):
+        loc = sys._getframe(1).f_locals
+        final.update(
+            rebuffer_time=float(rebuffer_time), start_up_time=float(start_up_time),
+            average_latency=float(average_latency),
+            global_time=float(loc["global_time"]), buffer_level=float(loc["buffer_level"]),
+            play_time=float(loc["play_time"]), play_id=int(loc["play_id"]),
+            chunk_id=int(loc["chunk_id"]),
+            bitrates=list(previous_bitrates),
+            bandwidths=[float(x) for x in loc["previous_bandwidths"]])
+        return orig(rebuffer_time, previous_bitrates, start_up_time, average_latency)
+
+    sim.calculate_qoe = spy
+    final["qoe"] = float(sim.run())
+    return abr.rec, final
+
+
+ENV_CONFIGS = {
+    # the BASELINE.json / SURVEY 8(d) bench shape
+    "env_bench_shape": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=48,
+        max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1],
+        speed=1.0, lanes=64, n_traces=8, trace_len=1000, bw=(0.2, 6.0), policy="random"),
+    # the mpc_test.py shape (L=1, 4-rate ladder)
+    "env_l1_ladder4": dict(
+        ladder=[1, 2.5, 5, 8], chunk_length=1, video_length=60,
+        max_buffer=20, start_up_length=2, interval=1.0, weights=[1, 0, 0, 0],
+        speed=1.0, lanes=32, n_traces=4, trace_len=1000, bw=(0.5, 10.0), policy="random"),
+    # max_buffer < start_up_length + L: buffer_full gates the next download; interval 0.5
+    "env_bufferfull_i05": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=2, video_length=24,
+        max_buffer=3.0, start_up_length=4, interval=0.5, weights=[4.3, 1, 1, 0.1],
+        speed=1.0, lanes=32, n_traces=4, trace_len=1000, bw=(2.0, 12.0), policy="random"),
+    # starved network + interval 0.3 (inexact division knife edges), heavy rebuffering
+    "env_starved_i03": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=16,
+        max_buffer=20, start_up_length=4, interval=0.3, weights=[4.3, 1, 1, 0.1],
+        speed=1.0, lanes=32, n_traces=4, trace_len=6000, bw=(0.1, 1.5), policy="random"),
+    # non-unit playback speed (no speed controller ships; a constant stands in)
+    "env_speed125": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=16,
+        max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1],
+        speed=1.25, lanes=16, n_traces=4, trace_len=1000, bw=(0.2, 6.0), policy="random"),
+    # constant policies (lowest / highest rate) with start offsets
+    "env_const_policy": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=12,
+        max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1],
+        speed=1.0, lanes=16, n_traces=4, trace_len=1000, bw=(0.2, 6.0), policy="const"),
+    # chunk_length 3 with interval 0.7: neither divides exactly
+    "env_l3_i07": dict(
+        ladder=[0.5, 1.0, 2.0, 3.5], chunk_length=3, video_length=20,
+        max_buffer=9, start_up_length=3, interval=0.7, weights=[2.0, 0.5, 1, 0.05],
+        speed=1.0, lanes=16, n_traces=4, trace_len=2000, bw=(0.3, 5.0), policy="random"),
+}
+
+
+def gen_env(name, cfg, S):
+    rng = random.Random(sum(map(ord, name)))
+    lo, hi = cfg["bw"]
+    # bandwidths rounded to float32 so text, oracle and device hold one value
+    traces = np.array([[np.float32(rng.uniform(lo, hi)) for _ in range(cfg["trace_len"])]
+                       for _ in range(cfg["n_traces"])], dtype=np.float64)
+    V, N, B = cfg["video_length"], cfg["lanes"], len(cfg["ladder"])
+    trace_id = np.array([i % cfg["n_traces"] for i in range(N)], dtype=np.int32)
+    offset = np.array([0 if i < cfg["n_traces"] else rng.randrange(cfg["trace_len"])
+                       for i in range(N)], dtype=np.int32)
+    if cfg["policy"] == "random":
+        actions = np.array([[rng.randrange(B) for _ in range(V)] for _ in range(N)], dtype=np.int32)
+    else:
+        actions = np.array([[(0 if (i % 2 == 0) else B - 1)] * V for i in range(N)], dtype=np.int32)
+    out = {k: np.zeros((N, V), np.float64) for k in STEP_F64}
+    out.update({k: np.zeros((N, V), np.int32) for k in STEP_I32})
+    out["arg_last_bitrate"] = np.zeros((N, V), np.int32)
+    out["arg_last_bandwidth"] = np.zeros((N, V), np.float64)
+    fin_f = ["qoe", "rebuffer_time", "start_up_time", "average_latency", "global_time",
+             "buffer_level", "play_time"]
+    fin = {"final_" + k: np.zeros(N, np.float64) for k in fin_f}
+    fin["final_play_id"] = np.zeros(N, np.int32)
+    fin["final_bandwidths"] = np.zeros((N, V), np.float64)
+    with tempfile.TemporaryDirectory() as td:
+        for i in range(N):
+            t = traces[trace_id[i]]
+            rot = np.concatenate([t[offset[i]:], t[:offset[i]]])
+            rec, final = run_lane(S, cfg, rot, [int(a) for a in actions[i]], td)
+            assert len(rec) == V and final["chunk_id"] == V
+            assert final["bitrates"] == [int(a) for a in actions[i]]
+            # D7: the fixture must stay inside the non-wrapping domain
+            assert final["global_time"] / cfg["interval"] < cfg["trace_len"] - 1
+            for s, r in enumerate(rec):
+                assert r["arg_hist_len"] == s
+                for k in out:
+                    out[k][i, s] = r[k]
+            for k in fin_f:
+                fin["final_" + k][i] = final[k]
+            fin["final_play_id"][i] = final["play_id"]
+            fin["final_bandwidths"][i] = final["bandwidths"]
+    meta = {k: v for k, v in cfg.items() if k not in ("bw",)}
+    meta["bw_range"] = list(cfg["bw"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), traces=traces, trace_id=trace_id,
+                        offset=offset, actions=actions, **out, **fin)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"{name}: {N} lanes x {V} steps; qoe[0]={fin['final_qoe'][0]!r}")
+
+
+# --------------------------------------------------------------------------
+# MPC goldens
+# --------------------------------------------------------------------------
+class _Chunk:
+    def __init__(self, bitrates, sizes):
+        self.bitrates, self.sizes = bitrates, sizes
+
+
+class _MPD:
+    def __init__(self, video_length, chunk_length, max_buffer, chunks):
+        self.video_length, self.chunk_length = video_length, chunk_length
+        self.max_buffer, self.chunks = max_buffer, chunks
+
+
+class _QoE:
+    def __init__(self, rebuffer_weight, variance_weight, startup_weight):
+        self.rebuffer_weight, self.variance_weight = rebuffer_weight, variance_weight
+        self.startup_weight = startup_weight
+
+
+class _ChunkInfo:
+    def __init__(self, chunk_number, previous_bitrate, previous_bandwidths, buffer_level):
+        self.chunk_number, self.previous_bitrate = chunk_number, previous_bitrate
+        self.previous_bandwidths, self.buffer_level = previous_bandwidths, buffer_level
+
+
+class _Player:
+    def __init__(self, mpd, qoe, ci):
+        self.mpd, self.qoe, self.ci = mpd, qoe, ci
+
+    def get_mpd(self):
+        return self.mpd
+
+    def get_qoe_metric(self):
+        return self.qoe
+
+    def get_next_chunk_info(self):
+        return self.ci
+
+
+def mpc_case(mpc, br, sz, L, max_buffer, wr, wv, ws, chunk, prev, hist, buf, H, full):
+    """One MPCBitrateController.next_bitrate() (mpc.py:181-186) + its internals."""
+    from scipy.optimize import brute
+    chunks = [_Chunk(list(br[i]), list(sz[i])) for i in range(len(br))]
+    ci = _ChunkInfo(chunk, prev, list(hist), buf)
+    ctl = mpc.MPCBitrateController(_Player(_MPD(len(br), L, max_buffer, chunks), _QoE(wr, wv, ws), ci))
+    ctl.horizon = H
+    a = ctl.next_bitrate()
+    pred = list(ctl.predicted_bandwidths)
+    hist_after = list(ci.previous_bandwidths)           # D9: grown by H
+    B = len(br[0])
+    # full grid with the SAME predicted bandwidths (no second prediction)
+    x0, fval, grid, Jout = brute(ctl.objective, (slice(0, B, 1),) * H, args=(ci,),
+                                 full_output=True, finish=None)
+    assert int(x0[0]) == a
+    flat = int(np.argmin(Jout.ravel()))
+    srt = np.sort(Jout.ravel())
+    return dict(action=a, argmin=[int(v) for v in np.atleast_1d(x0)], Jmin=float(fval), flat=flat,
+                gap=float(srt[1] - srt[0]), pred=pred, hist_len_after=len(hist_after),
+                hist_sum_inv_after=_suminv(hist_after),
+                Jout=Jout.ravel().copy() if full else None)
+
+
+def _suminv(vals):
+    s = 0
+    for x in vals:      # list order, int 0 start: mpc.py:86-88
+        s += 1 / x
+    return float(s)
+
+
+def gen_mpc(mpc):
+    # ---- known answer: the mpc_test.py fixture (mpc_test.py:52-72) ----
+    br4 = [1, 2.5, 5, 8]
+    ka = mpc_case(mpc, [br4] * 60, [br4] * 60, 1, 20, 1, 0, 0, 20, 1, [2, 2.5, 4, 6, 8], 20, 5, True)
+    known = dict(ladder=br4, video_length=60, chunk_length=1, max_buffer=20,
+                 weights=dict(rebuffer=1, variance=0, startup=0), chunk=20, prev_bitrate=1,
+                 history=[2, 2.5, 4, 6, 8], buffer=20, horizon=5,
+                 action=ka["action"], argmin=ka["argmin"], Jmin=ka["Jmin"], flat=ka["flat"],
+                 pred=ka["pred"], hist_len_after=ka["hist_len_after"],
+                 J_first=float(ka["Jout"][0]), J_last=float(ka["Jout"][-1]))
+    assert known["action"] == 2 and known["argmin"] == [2, 1, 3, 3, 3] and known["flat"] == 639
+    with open(os.path.join(OUT, "mpc_known_answer.json"), "w") as f:
+        json.dump(known, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "mpc_known_answer_J.npz"), Jout=ka["Jout"])
+    print("mpc known answer:", known["action"], known["argmin"], repr(known["Jmin"]))
+
+    # ---- random sweeps ----
+    rng = random.Random(20260404)
+    ladder6 = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
+    sweeps = [
+        # name, B-ladder, H, L, max_buffer, (wr,wv,ws), V, vbr, n_cases, n_full
+        ("mpc_b6h5_cbr", ladder6, 5, 4, 20, (4.3, 1, 0), 48, False, 192, 8),
+        ("mpc_b6h5_vbr", ladder6, 5, 4, 20, (4.3, 1, 0), 48, True, 96, 4),
+        ("mpc_b4h5_l1", br4, 5, 1, 20, (1, 0, 0), 60, False, 64, 4),
+        ("mpc_b6h3_smallbuf", ladder6, 3, 2, 5, (4.3, 1, 0.5), 24, True, 64, 4),
+        ("mpc_b3h2", [1, 2, 4], 2, 2, 10, (2, 1, 0), 10, False, 16, 16),  # H=1 crashes the reference (mpc.py:186 indexes a scalar)
+        ("mpc_b5h4", [0.5, 1, 2, 3, 5], 4, 2, 12, (3, 0.5, 0), 30, True, 48, 4),
+    ]
+    for name, lad, H, L, mb, (wr, wv, ws), V, vbr, n, nfull in sweeps:
+        B = len(lad)
+        if vbr:
+            br = [[b * rng.uniform(0.8, 1.2) for b in lad] for _ in range(V)]
+            sz = [[b * L * rng.uniform(0.7, 1.3) for b in row] for row in br]
+        else:
+            br = [list(lad)] * V
+            sz = [[b * L for b in lad]] * V
+        rec = dict(chunk=[], prev=[], buf=[], hist_n=[], hist_s=[], action=[], flat=[], Jmin=[],
+                   gap=[], pred=[], hist_n_after=[], hist_s_after=[], Jfull=[], hist_raw=[])
+        for c in range(n):
+            chunk = rng.randrange(0, V - H + 1)
+            prev = rng.randrange(B)
+            buf = rng.choice([0.0, rng.uniform(0, mb), rng.uniform(0, mb), float(mb)])
+            hl = rng.randrange(1, 12)
+            hist = [rng.uniform(0.2, 6.0) for _ in range(hl)]
+            r = mpc_case(mpc, br, sz, L, mb, wr, wv, ws, chunk, prev, hist, buf, H, c < nfull)
+            rec["chunk"].append(chunk); rec["prev"].append(prev); rec["buf"].append(buf)
+            rec["hist_n"].append(hl); rec["hist_s"].append(_suminv(hist))
+            rec["hist_raw"].append(hist + [0.0] * (12 - hl))
+            rec["action"].append(r["action"]); rec["flat"].append(r["flat"])
+            rec["Jmin"].append(r["Jmin"]); rec["gap"].append(r["gap"]); rec["pred"].append(r["pred"])
+            rec["hist_n_after"].append(r["hist_len_after"])
+            rec["hist_s_after"].append(r["hist_sum_inv_after"])
+            if c < nfull:
+                rec["Jfull"].append(r["Jout"])
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            br=np.array(br, np.float64), sz=np.array(sz, np.float64),
+            chunk=np.array(rec["chunk"], np.int32), prev=np.array(rec["prev"], np.int32),
+            buf=np.array(rec["buf"], np.float64), hist_n=np.array(rec["hist_n"], np.int32),
+            hist_s=np.array(rec["hist_s"], np.float64), hist_raw=np.array(rec["hist_raw"], np.float64),
+            action=np.array(rec["action"], np.int32), flat=np.array(rec["flat"], np.int32),
+            Jmin=np.array(rec["Jmin"], np.float64), gap=np.array(rec["gap"], np.float64),
+            pred=np.array(rec["pred"], np.float64),
+            hist_n_after=np.array(rec["hist_n_after"], np.int32),
+            hist_s_after=np.array(rec["hist_s_after"], np.float64),
+            Jfull=np.array(rec["Jfull"], np.float64))
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(dict(horizon=H, chunk_length=L, max_buffer=mb, rebuffer_weight=wr,
+                           variance_weight=wv, startup_weight=ws, video_length=V, n_rates=B,
+                           vbr=vbr, n_cases=n, n_full=nfull), f, indent=1)
+        ties = sum(1 for g in rec["gap"] if g == 0.0)
+        print(f"{name}: {n} cases, exact ties in {ties}, smallest nonzero gap "
+              f"{min([g for g in rec['gap'] if g > 0] or [0]):.3e}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    if a.only in ("", "mpc"):
+        gen_mpc(load_mpc())
+    if a.only in ("", "env"):
+        S = load_simulator_repaired()
+        for name, cfg in ENV_CONFIGS.items():
+            gen_env(name, cfg, S)
+
+
+if __name__ == "__main__":
+    main()
