@@ -1,0 +1,14 @@
+"""MI355X-native batched ABR environment + MPC lookahead.
+
+Importing the package loads the HIP library eagerly; if it has not been built
+the import fails (there is no CPU fallback).
+"""
+from . import _lib
+from .datamodel import MPD, Chunk, ChunkInfo, NetworkInfo, QOEMetric
+from .env import BatchedABREnv, obs_dict, pack_traces
+from .mpc import BatchedMPCController, EnvPlayer
+
+_lib.lib()   # fail loudly at import time when libabr_hip.so is missing
+
+__all__ = ["MPD", "Chunk", "ChunkInfo", "NetworkInfo", "QOEMetric", "BatchedABREnv",
+           "BatchedMPCController", "EnvPlayer", "obs_dict", "pack_traces"]

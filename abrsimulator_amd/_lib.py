@@ -1,0 +1,133 @@
+"""ctypes binding of the C ABI in include/abr_env.h (libabr_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or does not export the
+full ABI, importing the product fails loudly.  torch is imported first so that
+the library's libamdhip64.so.7 dependency resolves to the HIP runtime PyTorch
+already loaded (one runtime per process: streams and pointers are shared).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libabr_hip.so")
+
+ABI_VERSION = 1
+MAX_RATES = 16
+MAX_HORIZON = 8
+OBS_DIM = 8
+F64_DIM = 16
+
+OBS_ROWS = ["chunk_id", "last_bitrate", "last_bandwidth", "buffer_level", "global_time",
+            "play_time", "rebuffer_time", "start_up_time"]
+F64_ROWS = ["global_time", "rebuffer_time", "start_up_time", "play_time", "average_latency",
+            "buffer_level", "play_length", "last_bandwidth", "chunk_id", "play_id",
+            "last_bitrate", "flags", "hist_n", "hist_sum_inv", "tick", "download_time"]
+
+DONE_EPISODE, DONE_TIMEOUT, DONE_BADACT = 1, 2, 4
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [("n_rates", C.c_int32), ("video_length", C.c_int32),
+                ("chunk_length", C.c_double), ("max_buffer", C.c_double),
+                ("start_up_length", C.c_double), ("interval", C.c_double),
+                ("rebuffer_weight", C.c_double), ("variance_weight", C.c_double),
+                ("startup_weight", C.c_double), ("latency_weight", C.c_double),
+                ("speed", C.c_double), ("ladder", C.c_double * MAX_RATES),
+                ("max_ticks", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+class MpcConfig(C.Structure):
+    _fields_ = [("n_rates", C.c_int32), ("horizon", C.c_int32), ("video_length", C.c_int32),
+                ("clip_horizon", C.c_int32), ("chunk_length", C.c_double),
+                ("max_buffer", C.c_double), ("variance_weight", C.c_double),
+                ("rebuffer_weight", C.c_double), ("startup_weight", C.c_double)]
+
+
+class StateView(C.Structure):
+    _fields_ = [("n_lanes", C.c_int64), ("chunk_id", C.c_void_p), ("last_bitrate", C.c_void_p),
+                ("buffer_level", C.c_void_p), ("hist_n", C.c_void_p), ("hist_sum_inv", C.c_void_p),
+                ("done", C.c_void_p), ("action_hist", C.c_void_p), ("bw_hist", C.c_void_p)]
+
+
+# every symbol include/abr_env.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("abr_abi_version", C.c_int, []),
+    ("abr_last_error", C.c_char_p, []),
+    ("abr_env_workspace_bytes", C.c_int, [C.POINTER(EnvConfig), C.c_int64, C.POINTER(C.c_size_t)]),
+    ("abr_env_create", C.c_int, [C.POINTER(EnvConfig), _P, _P, _P, C.c_int32, C.c_int64, _P,
+                                 C.c_size_t, _P, C.POINTER(_P)]),
+    ("abr_env_destroy", C.c_int, [_P]),
+    ("abr_env_set_lane_id_base", C.c_int, [_P, C.c_int64]),
+    ("abr_env_reset", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("abr_env_step", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("abr_env_step_random", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
+    ("abr_env_episode_qoe", C.c_int, [_P, _P, _P]),
+    ("abr_env_observe_f64", C.c_int, [_P, _P, _P]),
+    ("abr_env_get_state", C.c_int, [_P, C.POINTER(StateView)]),
+    ("abr_mpc_select", C.c_int, [C.POINTER(MpcConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 C.c_int64, _P]),
+    ("abr_mpc_objective_grid", C.c_int, [C.POINTER(MpcConfig), C.c_int32, C.c_int32, C.c_double,
+                                         _P, _P, _P, _P, _P]),
+]
+
+_lib = None
+
+
+class AbrError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/abr_env.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, "abr_env.hip")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "abr_env.h")
+    stale = (not os.path.exists(SO_PATH)
+             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-B", "libabr_hip.so"])
+    return SO_PATH
+
+
+def lib():
+    """The loaded C-ABI library.  Raises ImportError if it is absent -- by design."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "abrsimulator_amd/csrc`). There is deliberately no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, res, args in SYMBOLS:
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise ImportError(f"{SO_PATH} does not export {name}; rebuild it") from e
+            fn.restype, fn.argtypes = res, args
+        if L.abr_abi_version() != ABI_VERSION:
+            raise ImportError(f"{SO_PATH}: ABI version {L.abr_abi_version()} != {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AbrError(f"abr C-ABI error {rc}: {lib().abr_last_error().decode()}")
+
+
+def ptr(t):
+    """data_ptr of a tensor (or None) after checking it is a contiguous device tensor."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor handed to the C ABI must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

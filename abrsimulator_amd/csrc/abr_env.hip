@@ -1,0 +1,1004 @@
+// abr_env.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/abr_env.h.
+//
+// Hot path restated from the reference (file:line into Elliotshui/ABRSimulator):
+//   K1 env_advance   Simulator.py:135-208   the dt = 0.01 s tick loop, one lane per thread
+//   K2 env_reset     Simulator.py:95-133    state init + idle ticks to the first ABR call site
+//   K3 mpc_select    mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H lookahead
+//   K4 episode_qoe   Simulator.py:79-86
+//
+// Exactness contract (DESIGN.md "Numerics"): every quantity that feeds a
+// decision in the reference (download_size >= target, buffer_level vs 0 /
+// max_buffer / start_up_length, int(global_time / x), play_length >= L) is
+// reproduced bit-for-bit: the lane-specific ones (downloaded_size,
+// buffer_level) as the same serial float64 additions, the lane-independent ones
+// (global_time and everything that is "k additions of dt starting from 0")
+// through tick tables computed once on the host in float64.  Compile with
+// -ffp-contract=off: an FMA would round bandwidth*dt + downloaded_size once
+// instead of twice (Simulator.py:160).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "abr_env.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return fail(ABR_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));       \
+    } while (0)
+
+extern "C" int abr_abi_version(void) { return ABR_ABI_VERSION; }
+extern "C" const char *abr_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// device-side parameter block (passed by value to every env kernel)
+// ---------------------------------------------------------------------------
+constexpr double kDt = 0.01;  // Simulator.py:133
+constexpr int kFlagStartUp = 1, kFlagBufEmpty = 2, kFlagBufFull = 4;
+
+struct EnvParams {
+    // config
+    int32_t n_rates, video_length, max_ticks, auto_reset;
+    int32_t play_ticks_per_chunk;  // P: first n with n-fold sum of speed*dt >= chunk_length (:185)
+    int32_t n_intervals;           // entries in interval_tick minus sentinel
+    double chunk_length, max_buffer, start_up_length;
+    double wr, wv, ws, wl;
+    double sd;                     // speed * dt, the product the reference forms each tick (:182)
+    double ladder[ABR_MAX_RATES];
+    int64_t n_lanes, lane_id_base;
+    // tables (device)
+    const double *G;               // G[n] = dt added n times to 0.0
+    const double *GP;              // same for sd (aliases G when speed == 1)
+    const int32_t *interval_tick;  // first tick k with int(G[k]/interval) >= j   (:158)
+    const int32_t *avail_tick;     // first tick k with int(G[k]/L) - 1 >= c      (:143)
+    // traces (device, caller-owned)
+    const double *traces;
+    const int64_t *trace_off;
+    const int32_t *trace_len;
+    // per-lane state, SoA (device, in the workspace)
+    double *buf, *last_bw, *hist_n, *hist_s;
+    long long *sumk;               // sum of tick indices of playing ticks (latency integral)
+    int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *plen, *play_id, *j, *tpos, *trace_id, *offset0;
+    int32_t *last_action, *n_su_obs, *n_rb_obs, *episode_no;
+    uint8_t *flags, *done;
+    uint8_t *action_hist;          // [V][n_lanes]
+    double *bw_hist;               // [V][n_lanes]
+    double *ep_qoe_terms;          // [4][n_lanes]: rebuffer, startup, avg latency, (unused) of the last finished episode
+    uint8_t *ep_actions;           // [V][n_lanes] actions of the last finished episode (auto_reset)
+};
+
+struct abr_env {
+    EnvParams p;
+    abr_env_config cfg;
+    size_t workspace_bytes;
+};
+
+// ---------------------------------------------------------------------------
+// philox4x32-10 (Salmon et al. 2011) -- counter-based, so shards reproduce the
+// unsharded run: ctr = (global lane id lo, hi, episode step, episode number)
+// ---------------------------------------------------------------------------
+__host__ __device__ inline uint32_t philox_action(uint64_t seed, uint64_t lane, uint32_t step,
+                                                  uint32_t episode, uint32_t n_rates) {
+    uint32_t c0 = (uint32_t)lane, c1 = (uint32_t)(lane >> 32), c2 = step, c3 = episode;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (uint32_t)(((uint64_t)c0 * n_rates) >> 32);   // multiply-shift into [0, n_rates)
+}
+
+// ---------------------------------------------------------------------------
+// K1/K2: the tick loop
+// ---------------------------------------------------------------------------
+// A lane in registers.  "Call site" = the instant inside tick k at which the
+// reference calls abr_controller.get_next_bitrate (Simulator.py:155): T1-T3 of
+// tick k are done, the download is not paused and download_time == 0.
+struct Lane {
+    double buf, dl, target, c;     // buffer_level, downloaded_size, target_size, bandwidth*dt
+    long long sumk;
+    int32_t k, chunk_id, n_su, n_rb, n_play, plen, play_id, j, tpos, n_dl;
+    int32_t avail_k, k_end, tlen, cur_action, last_action;
+    bool su, be, bf;               // start_up, buffer_empty, buffer_full
+    bool dlact, playing;           // !download_pause, !play_pause of the current tick
+    const double *trace;
+};
+
+__device__ inline void lane_init(Lane &s, const EnvParams &p, int32_t offset0) {
+    // Simulator.py:95-130
+    s.buf = 0.0; s.dl = 0.0; s.target = 0.0; s.sumk = 0;
+    s.k = 0; s.chunk_id = 0; s.n_su = 0; s.n_rb = 0; s.n_play = 0; s.plen = 0; s.play_id = 0;
+    s.n_dl = 0; s.cur_action = -1; s.last_action = -1;
+    s.su = true; s.be = true; s.bf = false;
+    s.dlact = false; s.playing = false;
+    // bandwidth index of tick 0 is int(0.0 / interval) = 0
+    s.j = 0;
+    s.tpos = offset0 % s.tlen;
+    s.avail_k = p.avail_tick[0];
+}
+
+// (re)load the per-interval constants: bandwidth*dt of interval j and the tick
+// at which interval j ends.  Advances j while k has passed the end (robust for
+// intervals shorter than a tick).
+__device__ inline void lane_refresh_interval(Lane &s, const EnvParams &p) {
+    int32_t ke = p.interval_tick[s.j + 1];
+    while (s.k >= ke) {
+        s.j++;
+        s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+        ke = p.interval_tick[s.j + 1];
+    }
+    s.k_end = ke;
+    s.c = s.trace[s.tpos] * kDt;   // bandwidth * dt  (:160; the product is formed first)
+}
+
+// T1-T3 of tick k (Simulator.py:137-149 with R2/R3)
+__device__ inline void tick_head(Lane &s) {
+    s.n_su += s.su ? 1 : 0;
+    s.n_rb += (!s.su && s.be) ? 1 : 0;
+    s.dlact = (s.k >= s.avail_k) && !s.bf;   // available_id >= chunk_id and not buffer_full
+    s.playing = !(s.be || s.su);
+}
+
+// T4-T9 of tick k (Simulator.py:152-208).  Returns kTickCompleted when a chunk
+// finished downloading in this tick, | kTickEnded when the episode ended.
+constexpr int kTickCompleted = 1, kTickEnded = 2;
+__device__ inline int tick_tail(Lane &s, const EnvParams &p, int64_t lane, double &bw_done) {
+    int ev = 0;
+    if (s.dlact) {
+        s.dl = s.dl + s.c;                                   // :160
+        s.n_dl++;                                            // :161 (download_time == G[n_dl])
+        if (s.dl >= s.target) {                              // :163
+            bw_done = s.dl / p.G[s.n_dl];                    // :164
+            p.bw_hist[(int64_t)s.chunk_id * p.n_lanes + lane] = bw_done;
+            p.action_hist[(int64_t)s.chunk_id * p.n_lanes + lane] = (uint8_t)s.cur_action;  // :165
+            s.last_action = s.cur_action;
+            s.chunk_id++;                                    // :166
+            s.dl = 0.0; s.n_dl = 0;                          // :167-168
+            s.buf += p.chunk_length;                         // :170
+            s.avail_k = p.avail_tick[s.chunk_id];
+            ev = kTickCompleted;
+        }
+    }
+    if (s.playing) {                                         // :174-187
+        s.sumk += s.k;                                       // latency integral, see lane_avg_latency
+        s.n_play++;
+        s.plen++;
+        s.buf -= p.sd;                                       // :184
+        if (s.plen == p.play_ticks_per_chunk) { s.plen = 0; s.play_id++; }   // :185-187
+    }
+    s.bf = (s.buf >= p.max_buffer);                          // :190-193
+    if (s.buf <= 0.0) { s.buf = 0.0; s.be = true; } else s.be = false;       // :194-198
+    if (s.su && s.buf >= p.start_up_length) s.su = false;    // :201-202
+    s.k++;                                                   // :205
+    if (s.chunk_id >= p.video_length) ev |= kTickEnded;      // :207-208
+    return ev;
+}
+
+// average_latency (Simulator.py:179-180).  The reference's recurrence telescopes
+// to sum(instant_latency) / play_time with instant_latency = global_time -
+// play_time at each playing tick.  We carry the sum as exact integers: the m-th
+// playing tick (m = 0..n_play-1) happened at tick k_m, so
+//   sum = sum_m (G[k_m] - GP[m])  ~=  dt * sum_m k_m - sd * n_play (n_play - 1) / 2
+// which differs from the reference only by float64 drift of the clocks
+// (<= 1e-11 relative, measured in tests); it feeds no decision.
+__device__ inline double lane_avg_latency(const EnvParams &p, long long sumk, int32_t n_play) {
+    if (n_play == 0) return 0.0;
+    double tri = (double)(((long long)n_play * (n_play - 1)) / 2);
+    return (kDt * (double)sumk - p.sd * tri) / p.GP[n_play];
+}
+
+__device__ inline void lane_load(Lane &s, const EnvParams &p, int64_t i) {
+    s.buf = p.buf[i]; s.sumk = p.sumk[i];
+    s.k = p.k[i]; s.chunk_id = p.chunk_id[i]; s.n_su = p.n_su[i]; s.n_rb = p.n_rb[i];
+    s.n_play = p.n_play[i]; s.plen = p.plen[i]; s.play_id = p.play_id[i];
+    s.j = p.j[i]; s.tpos = p.tpos[i];
+    s.last_action = p.last_action[i]; s.cur_action = -1;
+    uint8_t f = p.flags[i];
+    s.su = f & kFlagStartUp; s.be = f & kFlagBufEmpty; s.bf = f & kFlagBufFull;
+    s.dl = 0.0; s.n_dl = 0; s.target = 0.0;
+    s.avail_k = p.avail_tick[s.chunk_id < p.video_length ? s.chunk_id : p.video_length];
+}
+
+__device__ inline void lane_store(const Lane &s, const EnvParams &p, int64_t i) {
+    p.buf[i] = s.buf; p.sumk[i] = s.sumk;
+    p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
+    p.n_play[i] = s.n_play; p.plen[i] = s.plen; p.play_id[i] = s.play_id;
+    p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
+    p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
+                           (s.bf ? kFlagBufFull : 0));
+}
+
+__device__ inline void write_obs(const Lane &s, const EnvParams &p, int64_t i, float *obs,
+                                 double last_bw) {
+    if (!obs) return;
+    const int64_t n = p.n_lanes;
+    obs[ABR_OBS_CHUNK_ID * n + i] = (float)s.chunk_id;
+    obs[ABR_OBS_LAST_BITRATE * n + i] = (float)s.last_action;
+    obs[ABR_OBS_LAST_BANDWIDTH * n + i] = (float)last_bw;
+    obs[ABR_OBS_BUFFER_LEVEL * n + i] = (float)s.buf;
+    obs[ABR_OBS_GLOBAL_TIME * n + i] = (float)p.G[s.k];
+    obs[ABR_OBS_PLAY_TIME * n + i] = (float)p.GP[s.n_play];
+    obs[ABR_OBS_REBUFFER_TIME * n + i] = (float)p.G[s.n_rb];
+    obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
+}
+
+// MODE 0: reset (fresh lanes run to their first call site)
+// MODE 1: step  (one externally supplied action per lane)
+// MODE 2: fused random-policy rollout of n_steps decisions per lane
+//
+// One wave = 64 lanes, one lane per thread.  Loop nest:
+//   outer trip  = one trace interval (bandwidth constant): per-lane loads of
+//                 bandwidth and the interval's end tick happen here, together
+//                 for the whole wave, so the tick loop itself has no loads on
+//                 its critical path;
+//   inner trip  = one 0.01 s tick of every lane still running (exec-masked).
+// Interval ends are universal ticks, so after its first (partial) interval a
+// wave's lanes cross interval boundaries in lockstep.  Lanes retire from the
+// wave as their step finishes; `__any` (s_cbranch on the ballot) ends the loops.
+template <int MODE>
+__global__ __launch_bounds__(64) void env_advance_kernel(
+    EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
+    const int32_t *__restrict__ offset_in, const uint8_t *__restrict__ lane_mask,
+    float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
+    int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < p.n_lanes;
+    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    Lane s;
+    bool active = in_range;       // still has work in this launch
+    bool touched = in_range;      // state must be written back
+    bool fresh = (MODE == 0);     // running a new episode up to its first call site
+    bool at_call = false;         // needs an action before its next tick
+    uint8_t done = 0;
+    int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0, prev_action = -1;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
+    int32_t step_idx = 0;
+
+    if (in_range) {
+        if (MODE == 0) {
+            if (lane_mask && !lane_mask[i]) { active = false; touched = false; }
+            if (active) {
+                int32_t t = trace_id_in[i];
+                offset0 = offset_in ? offset_in[i] : 0;
+                p.trace_id[i] = t; p.offset0[i] = offset0;
+                s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+                lane_init(s, p, offset0);
+                tick_head(s);            // T1-T3 of tick 0
+            }
+        } else {
+            done = p.done[i];
+            int32_t t = p.trace_id[i];
+            offset0 = p.offset0[i];
+            s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+            lane_load(s, p, i);
+            n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
+            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+            if (done) active = false;
+            // a live lane sits at a call site: download not paused, playing as the flags say
+            s.dlact = true; s.playing = !(s.be || s.su);
+            at_call = active;
+        }
+    }
+
+    while (__any(active)) {
+        if (active) lane_refresh_interval(s, p);
+        bool run = active;
+        while (__any(run)) {
+            if (run && at_call) {
+                // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
+                int32_t a;
+                if (MODE == 1) a = actions[i];
+                else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i),
+                                                (uint32_t)s.chunk_id, (uint32_t)episode_no,
+                                                (uint32_t)p.n_rates);
+                if (MODE == 2 && actions_out) actions_out[(int64_t)step_idx * p.n_lanes + i] = a;
+                if (a < 0 || a >= p.n_rates) {
+                    done |= ABR_DONE_BADACT; active = false; run = false;
+                } else {
+                    prev_action = s.last_action;
+                    s.cur_action = a;
+                    s.target = p.ladder[a] * p.chunk_length;        // :156
+                    at_call = false;
+                }
+            }
+            if (run) {
+                double bw_done = 0.0;
+                const int ev = tick_tail(s, p, i, bw_done);
+                if (ev & kTickCompleted) {               // previous_bandwidths.append (:164)
+                    last_bw = bw_done;
+                    hist_s = hist_s + 1.0 / bw_done;     // sum(1/x), list order (mpc.py:86-88)
+                    hist_n = hist_n + 1.0;
+                }
+                const bool ended = ev & kTickEnded;
+                const bool timeout = !ended && (s.k >= p.max_ticks);
+                if (!(ended || timeout)) tick_head(s);   // T1-T3 of the next tick
+                const bool call = !(ended || timeout) && s.dlact && (s.n_dl == 0);
+                if (ended || timeout || call) {
+                    // ---- step boundary ----
+                    const int64_t o = (int64_t)step_idx * p.n_lanes + i;
+                    bool emit_obs = true;
+                    if (!fresh) {
+                        // per-step split of calculate_qoe (Simulator.py:83-85)
+                        // every boundary but a timeout follows exactly one completed chunk
+                        const double var = (prev_action >= 0 && !timeout)
+                                         ? fabs(p.ladder[s.last_action] - p.ladder[prev_action]) : 0.0;
+                        const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
+                                         p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
+                        if (ended) done |= ABR_DONE_EPISODE;
+                        if (timeout) done |= ABR_DONE_TIMEOUT;
+                        if (reward_out) reward_out[o] = (float)r;
+                        if (done_out) done_out[o] = done;
+                        n_su_obs = s.n_su; n_rb_obs = s.n_rb;
+                        if (ended || timeout) {
+                            p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
+                            p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                            p.ep_qoe_terms[2 * p.n_lanes + i] =
+                                lane_avg_latency(p, s.sumk, s.n_play);
+                            if (p.auto_reset && ended) {
+                                // re-arm: the step's obs is the new episode's first call site
+                                for (int c = 0; c < p.video_length; c++)
+                                    p.ep_actions[(int64_t)c * p.n_lanes + i] =
+                                        p.action_hist[(int64_t)c * p.n_lanes + i];
+                                lane_init(s, p, offset0);
+                                lane_refresh_interval(s, p);
+                                tick_head(s);
+                                episode_no++;
+                                n_su_obs = 0; n_rb_obs = 0;
+                                last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                                done = 0; fresh = true; emit_obs = false;
+                            }
+                        }
+                    } else if (timeout) {
+                        done |= ABR_DONE_TIMEOUT;
+                        if (MODE != 0 && done_out) done_out[o] = done;
+                    }
+                    if (emit_obs) {
+                        fresh = false;
+                        float *obs = obs_out ? obs_out + (int64_t)step_idx * ABR_OBS_DIM * p.n_lanes
+                                             : nullptr;
+                        write_obs(s, p, i, obs, last_bw);
+                        step_idx++;
+                        if (done || step_idx >= n_total) { active = false; run = false; }
+                        else at_call = true;         // fused: take the next action right away
+                    }
+                }
+                if (run && s.k >= s.k_end) run = false;  // interval over: back to the outer loop
+            }
+        }
+    }
+
+    if (touched) {
+        lane_store(s, p, i);
+        p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
+        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+        p.done[i] = done;
+        if (MODE != 0) {
+            // lanes that were already finished (or finished early in a fused launch)
+            // report their terminal record for the remaining steps
+            for (int32_t t = step_idx; t < n_total; t++) {
+                const int64_t o = (int64_t)t * p.n_lanes + i;
+                if (reward_out) reward_out[o] = 0.0f;
+                if (done_out) done_out[o] = done;
+                if (MODE == 2 && actions_out) actions_out[o] = -1;
+                if (obs_out)
+                    write_obs(s, p, i, obs_out + (int64_t)t * ABR_OBS_DIM * p.n_lanes, last_bw);
+            }
+        }
+    }
+}
+
+// K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
+__global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_lanes) return;
+    const uint8_t *acts = p.auto_reset ? p.ep_actions : p.action_hist;
+    double variance = 0.0;
+    for (int c = 0; c < p.video_length - 1; c++) {
+        int a0 = acts[(int64_t)c * p.n_lanes + i], a1 = acts[(int64_t)(c + 1) * p.n_lanes + i];
+        variance += fabs(p.ladder[a0] - p.ladder[a1]);                   // :82
+    }
+    qoe_out[i] = p.wr * p.ep_qoe_terms[0 * p.n_lanes + i] + p.wv * variance +
+                 p.ws * p.ep_qoe_terms[1 * p.n_lanes + i] +
+                 p.wl * p.ep_qoe_terms[2 * p.n_lanes + i];               // :83-86
+}
+
+__global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_lanes) return;
+    const int64_t n = p.n_lanes;
+    out[ABR_F64_GLOBAL_TIME * n + i] = p.G[p.k[i]];
+    out[ABR_F64_REBUFFER_TIME * n + i] = p.G[p.n_rb[i]];
+    out[ABR_F64_STARTUP_TIME * n + i] = p.G[p.n_su[i]];
+    out[ABR_F64_PLAY_TIME * n + i] = p.GP[p.n_play[i]];
+    out[ABR_F64_AVERAGE_LATENCY * n + i] = lane_avg_latency(p, p.sumk[i], p.n_play[i]);
+    out[ABR_F64_BUFFER_LEVEL * n + i] = p.buf[i];
+    out[ABR_F64_PLAY_LENGTH * n + i] = p.GP[p.plen[i]];
+    out[ABR_F64_LAST_BANDWIDTH * n + i] = p.last_bw[i];
+    out[ABR_F64_CHUNK_ID * n + i] = (double)p.chunk_id[i];
+    out[ABR_F64_PLAY_ID * n + i] = (double)p.play_id[i];
+    out[ABR_F64_LAST_BITRATE * n + i] = (double)p.last_action[i];
+    out[ABR_F64_FLAGS * n + i] = (double)p.flags[i];
+    out[ABR_F64_HIST_N * n + i] = p.hist_n[i];
+    out[ABR_F64_HIST_SUM_INV * n + i] = p.hist_s[i];
+    out[ABR_F64_TICK * n + i] = (double)p.k[i];
+    out[ABR_F64_DOWNLOAD_TIME * n + i] = 0.0;   // download_time is 0 at every call site (:154)
+}
+
+// ---------------------------------------------------------------------------
+// host side of the env ABI
+// ---------------------------------------------------------------------------
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Layout {
+    size_t G, GP, interval_tick, avail_tick;        // table offsets
+    size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms, ep_actions;
+    size_t total;
+    int32_t max_ticks, n_intervals;
+};
+
+static int32_t default_max_ticks(const abr_env_config *c) {
+    double per_chunk = ceil(c->chunk_length / kDt);
+    double mt = 32.0 * c->video_length * per_chunk;
+    if (mt > 16.0e6) mt = 16.0e6;
+    if (mt < 1024) mt = 1024;
+    return (int32_t)mt;
+}
+
+static int validate_cfg(const abr_env_config *c) {
+    if (!c) return fail(ABR_E_INVALID, "config is NULL");
+    if (c->n_rates < 1 || c->n_rates > ABR_MAX_RATES)
+        return fail(ABR_E_INVALID, "n_rates %d outside 1..%d", c->n_rates, ABR_MAX_RATES);
+    if (c->video_length < 1 || c->video_length > 65535)
+        return fail(ABR_E_INVALID, "video_length %d outside 1..65535", c->video_length);
+    if (!(c->chunk_length > 0) || !(c->interval > 0) || !(c->speed > 0))
+        return fail(ABR_E_INVALID, "chunk_length, interval and speed must be > 0");
+    if (!(c->max_buffer > 0)) return fail(ABR_E_INVALID, "max_buffer must be > 0");
+    if (!(c->start_up_length >= 0)) return fail(ABR_E_INVALID, "start_up_length must be >= 0");
+    if (c->chunk_length / kDt > 1.0e6)
+        return fail(ABR_E_UNSUPPORTED, "chunk_length %g s is more than 1e6 ticks", c->chunk_length);
+    for (int r = 0; r < c->n_rates; r++)
+        if (!(c->ladder[r] > 0)) return fail(ABR_E_INVALID, "ladder[%d] must be > 0", r);
+    return ABR_OK;
+}
+
+static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
+    int rc = validate_cfg(c);
+    if (rc) return rc;
+    if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
+    int32_t mt = c->max_ticks > 0 ? c->max_ticks : default_max_ticks(c);
+    double n_iv = (double)mt * kDt / c->interval + 4.0;
+    if (n_iv > 32.0e6)
+        return fail(ABR_E_UNSUPPORTED, "interval %g s needs a %g-entry tick table", c->interval, n_iv);
+    L->max_ticks = mt;
+    L->n_intervals = (int32_t)n_iv;
+    size_t o = 0;
+    const size_t A = 256;
+    size_t N = (size_t)n_lanes, V = (size_t)c->video_length;
+    L->G = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
+    L->GP = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
+    L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 2), A);
+    L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
+    L->f64_state = o; o = align_up(o + sizeof(double) * 4 * N, A);
+    L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);
+    L->i32_state = o; o = align_up(o + sizeof(int32_t) * 15 * N, A);
+    L->u8_state = o; o = align_up(o + 2 * N, A);
+    L->action_hist = o; o = align_up(o + V * N, A);
+    L->bw_hist = o; o = align_up(o + sizeof(double) * V * N, A);
+    L->ep_terms = o; o = align_up(o + sizeof(double) * 4 * N, A);
+    L->ep_actions = o; o = align_up(o + V * N, A);
+    L->total = o;
+    return ABR_OK;
+}
+
+extern "C" int abr_env_workspace_bytes(const abr_env_config *cfg, int64_t n_lanes,
+                                       size_t *bytes_out) {
+    Layout L;
+    int rc = compute_layout(cfg, n_lanes, &L);
+    if (rc) return rc;
+    if (!bytes_out) return fail(ABR_E_INVALID, "bytes_out is NULL");
+    *bytes_out = L.total;
+    return ABR_OK;
+}
+
+extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_dev,
+                              const int64_t *trace_off_dev, const int32_t *trace_len_dev,
+                              int32_t n_traces, int64_t n_lanes, void *workspace_dev,
+                              size_t workspace_bytes, void *stream, abr_env **env_out) {
+    Layout L;
+    int rc = compute_layout(cfg, n_lanes, &L);
+    if (rc) return rc;
+    if (!env_out) return fail(ABR_E_INVALID, "env_out is NULL");
+    if (!traces_dev || !trace_off_dev || !trace_len_dev || n_traces < 1)
+        return fail(ABR_E_INVALID, "trace arrays missing");
+    if (!workspace_dev || ((uintptr_t)workspace_dev & 255))
+        return fail(ABR_E_WORKSPACE, "workspace must be non-NULL and 256-B aligned");
+    if (workspace_bytes < L.total)
+        return fail(ABR_E_WORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, L.total);
+
+    // ---- universal tick tables, float64 on the host (SURVEY.md 7 "Hard parts" 1) ----
+    const int32_t mt = L.max_ticks;
+    std::vector<double> G((size_t)mt + 2), GP((size_t)mt + 2);
+    const double sd = cfg->speed * kDt;      // play_speed * dt as the reference forms it (:182)
+    {
+        double g = 0.0, gp = 0.0;            // global_time = 0.0 (:128); play_time = 0 (:115)
+        for (int32_t n = 0; n < mt + 2; n++) {
+            G[n] = g; GP[n] = gp;
+            g += kDt;                        // :205 (and :138,:140,:161)
+            gp += sd;                        // :182-183
+        }
+    }
+    std::vector<int32_t> itick((size_t)L.n_intervals + 2, INT_MAX);
+    {
+        int64_t jcur = 0;
+        for (int32_t k = 0; k <= mt && jcur < L.n_intervals + 2; k++) {
+            int64_t idx = (int64_t)(G[k] / cfg->interval);      // :158
+            while (jcur <= idx && jcur < L.n_intervals + 2) itick[jcur++] = k;
+        }
+    }
+    std::vector<int32_t> atick((size_t)cfg->video_length + 2, INT_MAX);
+    {
+        int64_t ccur = 0;
+        for (int32_t k = 0; k <= mt && ccur < cfg->video_length; k++) {
+            int64_t avail = (int64_t)(G[k] / cfg->chunk_length) - 1;   // :143
+            while (ccur <= avail && ccur < cfg->video_length) atick[ccur++] = k;
+        }
+    }
+    int32_t P = INT_MAX;
+    for (int32_t n = 1; n < mt + 2; n++)
+        if (GP[n] >= cfg->chunk_length) { P = n; break; }      // :185
+    if (P == INT_MAX)
+        return fail(ABR_E_UNSUPPORTED, "max_ticks %d too small to play one chunk", mt);
+
+    abr_env *e = new (std::nothrow) abr_env;
+    if (!e) return fail(ABR_E_INVALID, "out of host memory");
+    memset(e, 0, sizeof(*e));
+    e->cfg = *cfg;
+    e->workspace_bytes = L.total;
+    EnvParams &p = e->p;
+    p.n_rates = cfg->n_rates; p.video_length = cfg->video_length; p.max_ticks = mt;
+    p.auto_reset = cfg->auto_reset; p.play_ticks_per_chunk = P; p.n_intervals = L.n_intervals;
+    p.chunk_length = cfg->chunk_length; p.max_buffer = cfg->max_buffer;
+    p.start_up_length = cfg->start_up_length;
+    p.wr = cfg->rebuffer_weight; p.wv = cfg->variance_weight; p.ws = cfg->startup_weight;
+    p.wl = cfg->latency_weight; p.sd = sd;
+    for (int r = 0; r < ABR_MAX_RATES; r++) p.ladder[r] = cfg->ladder[r];
+    p.n_lanes = n_lanes; p.lane_id_base = 0;
+    char *w = (char *)workspace_dev;
+    p.G = (const double *)(w + L.G); p.GP = (const double *)(w + L.GP);
+    p.interval_tick = (const int32_t *)(w + L.interval_tick);
+    p.avail_tick = (const int32_t *)(w + L.avail_tick);
+    p.traces = traces_dev; p.trace_off = trace_off_dev; p.trace_len = trace_len_dev;
+    const size_t N = (size_t)n_lanes;
+    double *f = (double *)(w + L.f64_state);
+    p.buf = f; p.last_bw = f + N; p.hist_n = f + 2 * N; p.hist_s = f + 3 * N;
+    p.sumk = (long long *)(w + L.i64_state);
+    int32_t *q = (int32_t *)(w + L.i32_state);
+    p.k = q; p.chunk_id = q + N; p.n_su = q + 2 * N; p.n_rb = q + 3 * N; p.n_play = q + 4 * N;
+    p.plen = q + 5 * N; p.play_id = q + 6 * N; p.j = q + 7 * N; p.tpos = q + 8 * N;
+    p.trace_id = q + 9 * N; p.offset0 = q + 10 * N; p.last_action = q + 11 * N;
+    p.n_su_obs = q + 12 * N; p.n_rb_obs = q + 13 * N; p.episode_no = q + 14 * N;
+    uint8_t *u = (uint8_t *)(w + L.u8_state);
+    p.flags = u; p.done = u + N;
+    p.action_hist = (uint8_t *)(w + L.action_hist);
+    p.bw_hist = (double *)(w + L.bw_hist);
+    p.ep_qoe_terms = (double *)(w + L.ep_terms);
+    p.ep_actions = (uint8_t *)(w + L.ep_actions);
+
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t he;
+#define UP(dst, vec)                                                                           \
+    he = hipMemcpyAsync((void *)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]),          \
+                        hipMemcpyHostToDevice, st);                                            \
+    if (he != hipSuccess) { delete e; return fail(ABR_E_HIP, "table upload: %s", hipGetErrorString(he)); }
+    UP(p.G, G) UP(p.GP, GP) UP(p.interval_tick, itick) UP(p.avail_tick, atick)
+#undef UP
+    he = hipMemsetAsync(w + L.f64_state, 0, L.total - L.f64_state, st);
+    if (he == hipSuccess) he = hipMemsetAsync(p.done, ABR_DONE_EPISODE, N, st);  // not reset yet
+    if (he == hipSuccess) he = hipStreamSynchronize(st);   // host vectors die at return
+    if (he != hipSuccess) { delete e; return fail(ABR_E_HIP, "workspace init: %s", hipGetErrorString(he)); }
+    *env_out = e;
+    return ABR_OK;
+}
+
+extern "C" int abr_env_destroy(abr_env *env) {
+    delete env;
+    return ABR_OK;
+}
+
+// lane id base for the counter-based policy when lanes are a shard of a bigger job
+extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    env->p.lane_id_base = base;
+    return ABR_OK;
+}
+
+static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
+
+extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
+                             const int32_t *start_offset_dev, const uint8_t *lane_mask_dev,
+                             float *obs_out_dev, void *stream) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (!trace_id_dev) return fail(ABR_E_INVALID, "trace_id_dev is NULL");
+    hipLaunchKernelGGL(env_advance_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+                       (hipStream_t)stream, env->p, nullptr, trace_id_dev, start_offset_dev,
+                       lane_mask_dev, obs_out_dev, nullptr, nullptr, nullptr, 0, 0ull);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs_out_dev,
+                            float *reward_out_dev, uint8_t *done_out_dev, void *stream) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
+    hipLaunchKernelGGL(env_advance_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+                       (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
+                       obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed,
+                                   float *obs_out_dev, float *reward_out_dev,
+                                   uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
+    hipLaunchKernelGGL(env_advance_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+                       (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
+                       obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_env_episode_qoe(abr_env *env, double *qoe_out_dev, void *stream) {
+    if (!env || !qoe_out_dev) return fail(ABR_E_INVALID, "NULL argument");
+    hipLaunchKernelGGL(episode_qoe_kernel, dim3((unsigned)((env->p.n_lanes + 255) / 256)),
+                       dim3(256), 0, (hipStream_t)stream, env->p, qoe_out_dev);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream) {
+    if (!env || !out_dev) return fail(ABR_E_INVALID, "NULL argument");
+    hipLaunchKernelGGL(observe_f64_kernel, dim3((unsigned)((env->p.n_lanes + 255) / 256)),
+                       dim3(256), 0, (hipStream_t)stream, env->p, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_env_get_state(abr_env *env, abr_env_state_view *v) {
+    if (!env || !v) return fail(ABR_E_INVALID, "NULL argument");
+    const EnvParams &p = env->p;
+    v->n_lanes = p.n_lanes; v->chunk_id = p.chunk_id; v->last_bitrate = p.last_action;
+    v->buffer_level = p.buf; v->hist_n = p.hist_n; v->hist_sum_inv = p.hist_s; v->done = p.done;
+    v->action_hist = p.action_hist; v->bw_hist = p.bw_hist;
+    return ABR_OK;
+}
+
+// ===========================================================================
+// K3: MPC lookahead (mpc.py)
+// ===========================================================================
+struct MpcParams {
+    int32_t B, H, V, clip;
+    double L, max_buffer, wv, wr, ws;
+    int64_t n_lanes;
+    const int32_t *chunk, *prev;
+    const double *buffer;
+    double *hist_n, *hist_s;
+    const double *br, *sz;
+    const uint8_t *mask;
+    int32_t *action_out, *flat_out;
+    double *J_out;
+};
+
+__device__ inline double pymax0(double x) { return (x > 0.0) ? x : 0.0; }   // Python max(0, x)
+
+// per-lane tables in LDS, [level][rate]:
+//   brv[i][r] = bitrates[i][r]                      (chunk c+i's ladder, mpc.py:127-128)
+//   rbt[i][r] = max(0, sizes[i][r], L) / C_hat[i]    (mpc.py:151-152, D10)
+//   tdl[i][r] = sizes_of_CURRENT_chunk[r] / C_hat[i] (mpc.py:107,116 via :155-156, D11)
+struct MpcLds {
+    const double *brv, *rbt, *tdl;
+    double L, max_buffer, wv, wr;
+    int B, heff;
+};
+
+struct Best { double J; int32_t flat; };
+
+// Depth-first enumeration with prefix sharing: the partial sums of objective()
+// (mpc.py:144-156) after level i depend only on R[0..i], and are formed in the
+// same order as the reference forms them, so every leaf value is bit-identical
+// to a from-scratch evaluation.  Leaves are visited in increasing flat index;
+// strict `<` keeps the first minimum (numpy argmin on the raveled C-order grid).
+template <int LVL, int H>
+__device__ inline void mpc_dfs(const MpcLds &t, double q, double v, double rb, double buf,
+                               int prev_r, int32_t flat, Best &best) {
+    const double *brv = t.brv + LVL * t.B, *rbt = t.rbt + LVL * t.B, *tdl = t.tdl + LVL * t.B;
+    const double br_prev = brv[prev_r];
+    const bool leaf = (LVL == H - 1) || (LVL == t.heff - 1);
+    for (int r = 0; r < t.B; r++) {
+        const double b = brv[r];
+        const double q2 = q + b;                              // :146
+        const double v2 = v + fabs(b - br_prev);              // :148-149
+        const double rb2 = rb + (rbt[r] - buf);               // :151-152
+        const int32_t f2 = flat * t.B + r;
+        if (leaf) {
+            const double J = -((q2 - t.wv * v2) - t.wr * rb2);   // :158-162 (startup term is 0)
+            if (J < best.J) { best.J = J; best.flat = f2; }
+        } else {
+            if constexpr (LVL + 1 < H) {
+                const double tmp = pymax0(buf - tdl[r]);                       // :107,:116
+                const double wait = pymax0(tmp + t.L - t.max_buffer);          // :108-109
+                const double nb = pymax0(tmp + t.L - wait);                    // :117
+                mpc_dfs<LVL + 1, H>(t, q2, v2, rb2, nb, r, f2, best);
+            }
+        }
+    }
+}
+
+constexpr int kMpcLanesPerBlock = 16;
+
+// Threads of a block: (lane-in-block, prefix) pairs.  D = number of leading
+// levels fixed per thread (2 when H >= 3, else 1) -> T = B^D threads per lane.
+template <int H>
+__global__ void mpc_select_kernel(MpcParams p, int T, int D) {
+    extern __shared__ double lds[];
+    const int B = p.B;
+    const int HB = H * B;
+    // layout per lane-in-block: brv[HB] rbt[HB] tdl[HB] pred[H] | then bestJ[T], bestF[T]
+    const int per_lane = 3 * HB + H;
+    double *tab = lds;
+    double *bestJ = lds + kMpcLanesPerBlock * per_lane;
+    int32_t *bestF = (int32_t *)(bestJ + kMpcLanesPerBlock * T);
+    __shared__ int32_t heff_s[kMpcLanesPerBlock];
+
+    const int tid = threadIdx.x;
+    const int li = tid / T;               // lane in block
+    const int pre = tid - li * T;         // prefix id
+    const int64_t lane = (int64_t)blockIdx.x * kMpcLanesPerBlock + li;
+    const bool valid = (li < kMpcLanesPerBlock) && (lane < p.n_lanes) &&
+                       !(p.mask && !p.mask[lane]);
+    double *my = tab + (li < kMpcLanesPerBlock ? li : 0) * per_lane;
+
+    // ---- phase 1: harmonic predictor, one thread per lane (mpc.py:81-93) ----
+    if (valid && pre == 0) {
+        double n = p.hist_n[lane], S = p.hist_s[lane];
+        for (int i = 0; i < H; i++) {
+            double tp = n / S;            // history_size / sum_inverse  (:90)
+            my[3 * HB + i] = tp;
+            S = S + 1.0 / tp;             // throughput_values.append(tp): next pass sums it last
+            n = n + 1.0;
+        }
+        p.hist_n[lane] = n; p.hist_s[lane] = S;        // D9: the caller's list has grown by H
+        int c = p.chunk[lane];
+        int he = H;
+        if (c + H > p.V) he = p.clip ? (p.V - c) : 0;  // D12
+        if (he < 0) he = 0;
+        heff_s[li] = he;
+    }
+    __syncthreads();
+    // ---- phase 2: the per-(level, rate) tables, 60 divisions per lane spread over T threads ----
+    if (valid) {
+        const int c = p.chunk[lane];
+        const int he = heff_s[li];
+        for (int e = pre; e < HB; e += T) {
+            const int i = e / B, r = e - i * B;
+            if (i < he) {
+                const double pr = my[3 * HB + i];
+                const double s_i = p.sz[(int64_t)(c + i) * B + r];
+                double m = 0.0;
+                if (s_i > m) m = s_i;
+                if (p.L > m) m = p.L;                      // max(0, size, chunk_length)
+                my[e] = p.br[(int64_t)(c + i) * B + r];
+                my[HB + e] = m / pr;
+                my[2 * HB + e] = p.sz[(int64_t)c * B + r] / pr;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: each thread walks its prefix, then enumerates its subtree ----
+    Best best; best.J = INFINITY; best.flat = 0x7fffffff;
+    if (valid && heff_s[li] > 0) {
+        MpcLds t;
+        t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
+        t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B;
+        t.heff = heff_s[li];
+        double q = 0.0, v = 0.0, rb = 0.0, buf = p.buffer[lane];
+        int prev_r = p.prev[lane];
+        int32_t flat = 0;
+        bool ok = true, is_leaf = false;
+        // digits of the prefix, most significant first
+        int digs[2];
+        if (D == 2) { digs[0] = pre / B; digs[1] = pre - digs[0] * B; } else { digs[0] = pre; digs[1] = 0; }
+        for (int lvl = 0; lvl < D && ok && !is_leaf; lvl++) {
+            const int r = digs[lvl];
+            const double *brv = t.brv + lvl * B;
+            const double b = brv[r];
+            const double bp = brv[prev_r];
+            q = q + b; v = v + fabs(b - bp); rb = rb + (t.rbt[lvl * B + r] - buf);
+            flat = flat * B + r;
+            if (lvl == t.heff - 1) {
+                // clipped horizon ends inside the prefix: only all-zero remainders are real combos
+                for (int l2 = lvl + 1; l2 < D; l2++) if (digs[l2] != 0) ok = false;
+                is_leaf = true;
+            } else {
+                const double tmp = pymax0(buf - t.tdl[lvl * B + r]);
+                const double wait = pymax0(tmp + t.L - t.max_buffer);
+                buf = pymax0(tmp + t.L - wait);
+                prev_r = r;
+            }
+        }
+        if (ok) {
+            if (is_leaf) {
+                best.J = -((q - t.wv * v) - t.wr * rb); best.flat = flat;
+            } else if (D == 2) {
+                if constexpr (H >= 3) mpc_dfs<2, H>(t, q, v, rb, buf, prev_r, flat, best);
+            } else {
+                if constexpr (H >= 2) mpc_dfs<1, H>(t, q, v, rb, buf, prev_r, flat, best);
+            }
+        }
+    }
+    if (li < kMpcLanesPerBlock) { bestJ[li * T + pre] = best.J; bestF[li * T + pre] = best.flat; }
+    __syncthreads();
+    // ---- phase 4: arg-min over the T prefixes of a lane (ascending prefix = ascending flat) ----
+    if (valid && pre == 0) {
+        double bj = INFINITY; int32_t bf = 0x7fffffff; bool have = false;
+        for (int q2 = 0; q2 < T; q2++) {
+            const double J = bestJ[li * T + q2];
+            const int32_t f = bestF[li * T + q2];
+            if (f == 0x7fffffff) continue;
+            if (!have || J < bj) { bj = J; bf = f; have = true; }
+        }
+        const int he = heff_s[li];
+        int32_t act = -1;
+        if (have) {
+            int32_t lead = 1;
+            for (int i = 1; i < he; i++) lead *= B;
+            act = bf / lead;                                   // int(result[0])  mpc.py:186
+        }
+        p.action_out[lane] = act;
+        if (p.flat_out) p.flat_out[lane] = have ? bf : -1;
+        if (p.J_out) p.J_out[lane] = have ? bj : NAN;
+    }
+}
+
+static int validate_mpc(const abr_mpc_config *c) {
+    if (!c) return fail(ABR_E_INVALID, "mpc config is NULL");
+    if (c->n_rates < 1 || c->n_rates > ABR_MAX_RATES)
+        return fail(ABR_E_INVALID, "n_rates %d outside 1..%d", c->n_rates, ABR_MAX_RATES);
+    if (c->horizon < 2 || c->horizon > ABR_MAX_HORIZON)
+        return fail(ABR_E_INVALID, "horizon %d outside 2..%d", c->horizon, ABR_MAX_HORIZON);
+    double combos = pow((double)c->n_rates, (double)c->horizon);
+    if (combos > 2.0e9) return fail(ABR_E_UNSUPPORTED, "n_rates^horizon = %g exceeds int32", combos);
+    if (c->video_length < 1) return fail(ABR_E_INVALID, "video_length must be >= 1");
+    return ABR_OK;
+}
+
+template <int H>
+static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
+    const int threads = ((kMpcLanesPerBlock * T + 63) / 64) * 64;
+    const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);
+    const size_t lds = kMpcLanesPerBlock * per_lane +
+                       (size_t)kMpcLanesPerBlock * T * (sizeof(double) + sizeof(int32_t));
+    const unsigned grid = (unsigned)((p.n_lanes + kMpcLanesPerBlock - 1) / kMpcLanesPerBlock);
+    hipLaunchKernelGGL(mpc_select_kernel<H>, dim3(grid), dim3(threads), lds, st, p, T, D);
+}
+
+extern "C" int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
+                              const int32_t *prev_bitrate_dev, const double *buffer_dev,
+                              double *hist_n_dev, double *hist_sum_inv_dev,
+                              const double *br_table_dev, const double *sz_table_dev,
+                              const uint8_t *lane_mask_dev, int32_t *action_out_dev,
+                              int32_t *best_flat_out_dev, double *best_J_out_dev, int64_t n_lanes,
+                              void *stream) {
+    int rc = validate_mpc(cfg);
+    if (rc) return rc;
+    if (!chunk_dev || !prev_bitrate_dev || !buffer_dev || !hist_n_dev || !hist_sum_inv_dev ||
+        !br_table_dev || !sz_table_dev || !action_out_dev)
+        return fail(ABR_E_INVALID, "NULL device pointer");
+    if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
+    MpcParams p;
+    p.B = cfg->n_rates; p.H = cfg->horizon; p.V = cfg->video_length; p.clip = cfg->clip_horizon;
+    p.L = cfg->chunk_length; p.max_buffer = cfg->max_buffer; p.wv = cfg->variance_weight;
+    p.wr = cfg->rebuffer_weight; p.ws = cfg->startup_weight; p.n_lanes = n_lanes;
+    p.chunk = chunk_dev; p.prev = prev_bitrate_dev; p.buffer = buffer_dev;
+    p.hist_n = hist_n_dev; p.hist_s = hist_sum_inv_dev; p.br = br_table_dev; p.sz = sz_table_dev;
+    p.mask = lane_mask_dev; p.action_out = action_out_dev; p.flat_out = best_flat_out_dev;
+    p.J_out = best_J_out_dev;
+    const int D = (p.H >= 3) ? 2 : 1;
+    int T = p.B; if (D == 2) T *= p.B;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.H) {
+        case 2: launch_mpc<2>(p, T, D, st); break;
+        case 3: launch_mpc<3>(p, T, D, st); break;
+        case 4: launch_mpc<4>(p, T, D, st); break;
+        case 5: launch_mpc<5>(p, T, D, st); break;
+        case 6: launch_mpc<6>(p, T, D, st); break;
+        case 7: launch_mpc<7>(p, T, D, st); break;
+        case 8: launch_mpc<8>(p, T, D, st); break;
+        default: return fail(ABR_E_INVALID, "horizon %d", p.H);
+    }
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+// Diagnostic: every combo evaluated from scratch by its own thread, literally as
+// objective() does (mpc.py:120-162) -- no tables, no prefix sharing.  Used by the
+// tests as an independent check of the DFS kernel's arithmetic.
+__global__ void mpc_grid_kernel(int B, int H, int V, double L, double max_buffer, double wv,
+                                double wr, int chunk, int prev, double buffer,
+                                const double *__restrict__ pred, const double *__restrict__ br,
+                                const double *__restrict__ sz, double *__restrict__ J_out,
+                                int64_t total) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total) return;
+    int R[ABR_MAX_HORIZON + 1];
+    {
+        int64_t t = f;
+        for (int i = H; i >= 1; i--) { R[i] = (int)(t % B); t /= B; }
+        R[0] = prev;
+    }
+    double q = 0.0, v = 0.0, rb = 0.0, buf = buffer;
+    for (int i = 0; i < H; i++) {
+        const double *bri = br + (int64_t)(chunk + i) * B;
+        const double *szi = sz + (int64_t)(chunk + i) * B;
+        q += bri[R[i + 1]];
+        v += fabs(bri[R[i + 1]] - bri[R[i]]);
+        double m = 0.0;
+        if (szi[R[i + 1]] > m) m = szi[R[i + 1]];
+        if (L > m) m = L;
+        rb += (m / pred[i] - buf);
+        if (i != H - 1) {
+            const double cs = sz[(int64_t)chunk * B + R[i + 1]];
+            const double nb0 = pymax0(buf - cs / pred[i]);
+            const double wait = pymax0(nb0 + L - max_buffer);
+            buf = pymax0(nb0 + L - wait);
+        }
+    }
+    J_out[f] = -((q - wv * v) - wr * rb);
+    (void)V;
+}
+
+extern "C" int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk,
+                                      int32_t prev_bitrate, double buffer_level,
+                                      const double *pred_dev, const double *br_table_dev,
+                                      const double *sz_table_dev, double *J_out_dev, void *stream) {
+    int rc = validate_mpc(cfg);
+    if (rc) return rc;
+    if (!pred_dev || !br_table_dev || !sz_table_dev || !J_out_dev)
+        return fail(ABR_E_INVALID, "NULL device pointer");
+    if (chunk < 0 || chunk + cfg->horizon > cfg->video_length)
+        return fail(ABR_E_INVALID, "chunk %d + horizon %d exceeds video_length %d (mpc.py:126 raises)",
+                    chunk, cfg->horizon, cfg->video_length);
+    int64_t total = 1;
+    for (int i = 0; i < cfg->horizon; i++) total *= cfg->n_rates;
+    hipLaunchKernelGGL(mpc_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, cfg->n_rates, cfg->horizon, cfg->video_length,
+                       cfg->chunk_length, cfg->max_buffer, cfg->variance_weight,
+                       cfg->rebuffer_weight, chunk, prev_bitrate, buffer_level, pred_dev,
+                       br_table_dev, sz_table_dev, J_out_dev, total);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}

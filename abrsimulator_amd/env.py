@@ -1,0 +1,225 @@
+"""BatchedABREnv: the reference's Simulator.run() tick loop (Simulator.py:93-210)
+turned inside out into reset()/step(actions) over many independent lanes.
+
+Host Python only holds PyTorch-ROCm tensors and calls the C ABI
+(include/abr_env.h); all simulation runs in the HIP kernels of csrc/abr_env.hip.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import F64_DIM, F64_ROWS, OBS_DIM, OBS_ROWS
+from .datamodel import MPD, NetworkInfo, QOEMetric
+
+
+def pack_traces(traces: Sequence, device):
+    """Ragged list of bandwidth traces -> (flat f64, offsets i64, lengths i32) on `device`."""
+    ts = [torch.as_tensor(t, dtype=torch.float64).reshape(-1) for t in traces]
+    if not ts or any(t.numel() == 0 for t in ts):
+        raise ValueError("every trace needs at least one bandwidth sample")
+    lens = torch.tensor([t.numel() for t in ts], dtype=torch.int32)
+    off = torch.zeros(len(ts), dtype=torch.int64)
+    off[1:] = torch.cumsum(lens[:-1].to(torch.int64), 0)
+    flat = torch.cat(ts)
+    return flat.to(device), off.to(device), lens.to(device)
+
+
+class BatchedABREnv:
+    """n_lanes independent players, one per GPU thread.
+
+    mpd / qoe_metric / network_info carry the reference's field names
+    (datamodel.py).  reset() returns the observation at each lane's first
+    get_next_bitrate call site (Simulator.py:155); step(actions) supplies that
+    call's return value and returns (obs, reward, done) at the next one.
+    Observations are float32 [OBS_DIM, n_lanes] (rows: _lib.OBS_ROWS); the exact
+    float64 state is available through observe_f64() and state_view().
+    """
+
+    def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
+                 device="cuda", speed: float = 1.0, auto_reset: bool = False, max_ticks: int = 0,
+                 lane_id_base: int = 0):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("BatchedABREnv runs on a ROCm device only (no CPU path exists)")
+        self.n_lanes = int(n_lanes)
+        self.mpd, self.qoe_metric, self.network_info = mpd, qoe_metric, network_info
+        ladder = mpd.ladder()
+        cfg = _lib.EnvConfig()
+        cfg.n_rates, cfg.video_length = len(ladder), int(mpd.video_length)
+        cfg.chunk_length, cfg.max_buffer = float(mpd.chunk_length), float(mpd.max_buffer)
+        cfg.start_up_length, cfg.interval = float(mpd.start_up_length), float(network_info.interval)
+        cfg.rebuffer_weight = float(qoe_metric.rebuffer_weight)
+        cfg.variance_weight = float(qoe_metric.variance_weight)
+        cfg.startup_weight = float(qoe_metric.startup_weight)
+        cfg.latency_weight = float(getattr(qoe_metric, "latency_weight", 0.0))
+        cfg.speed = float(speed)
+        if len(ladder) > _lib.MAX_RATES:
+            raise ValueError(f"at most {_lib.MAX_RATES} bitrates")
+        for i, b in enumerate(ladder):
+            cfg.ladder[i] = b
+        cfg.max_ticks, cfg.auto_reset = int(max_ticks), int(bool(auto_reset))
+        self.cfg = cfg
+        self.n_rates, self.video_length = cfg.n_rates, cfg.video_length
+
+        bw = network_info.bandwidths
+        if torch.is_tensor(bw):
+            bw = [bw] if bw.dim() == 1 else list(bw)
+        elif len(bw) > 0 and not hasattr(bw[0], "__len__"):
+            bw = [bw]              # one trace given as a flat list of floats
+        with torch.cuda.device(self.device):
+            self.traces, self.trace_off, self.trace_len = pack_traces(bw, self.device)
+            self.n_traces = int(self.trace_len.numel())
+            nbytes = C.c_size_t()
+            _lib.check(self.lib.abr_env_workspace_bytes(C.byref(cfg), self.n_lanes, C.byref(nbytes)))
+            self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            assert self.workspace.data_ptr() % 256 == 0
+            h = C.c_void_p()
+            _lib.check(self.lib.abr_env_create(
+                C.byref(cfg), _lib.ptr(self.traces), _lib.ptr(self.trace_off),
+                _lib.ptr(self.trace_len), self.n_traces, self.n_lanes, _lib.ptr(self.workspace),
+                nbytes.value, self._stream(), C.byref(h)))
+        self._h = h
+        if lane_id_base:
+            _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
+        self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(self.n_lanes, dtype=torch.float32, device=self.device)
+        self.done = torch.zeros(self.n_lanes, dtype=torch.uint8, device=self.device)
+        self.trace_id = None
+        self.start_offset = None
+
+    # -- plumbing ----------------------------------------------------------
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.abr_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _i32(self, t, name):
+        t = torch.as_tensor(t, device=self.device)
+        if t.dtype != torch.int32:
+            t = t.to(torch.int32)
+        t = t.contiguous()
+        if t.shape != (self.n_lanes,):
+            raise ValueError(f"{name} must have shape ({self.n_lanes},), got {tuple(t.shape)}")
+        return t
+
+    # -- the step surface --------------------------------------------------
+    def reset(self, trace_id=None, start_offset=None, mask=None):
+        """Simulator.py:95-133 + idle ticks to the first ABR call.  Default
+        assignment: lane i -> trace i % n_traces, offset 0."""
+        if trace_id is None:
+            trace_id = torch.arange(self.n_lanes, device=self.device, dtype=torch.int32) % self.n_traces
+        self.trace_id = self._i32(trace_id, "trace_id")
+        if int(self.trace_id.min()) < 0 or int(self.trace_id.max()) >= self.n_traces:
+            raise ValueError("trace_id out of range")
+        if start_offset is None:
+            start_offset = torch.zeros(self.n_lanes, dtype=torch.int32, device=self.device)
+        self.start_offset = self._i32(start_offset, "start_offset")
+        if int(self.start_offset.min()) < 0:
+            raise ValueError("start_offset must be >= 0")
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        _lib.check(self.lib.abr_env_reset(self._h, _lib.ptr(self.trace_id),
+                                          _lib.ptr(self.start_offset), _lib.ptr(m),
+                                          _lib.ptr(self.obs), self._stream()))
+        return self.obs
+
+    def step(self, actions):
+        """One chunk per lane.  Returns (obs f32[OBS_DIM,N], reward f32[N], done u8[N]);
+        the tensors are reused across calls."""
+        a = self._i32(actions, "actions")
+        _lib.check(self.lib.abr_env_step(self._h, _lib.ptr(a), _lib.ptr(self.obs),
+                                         _lib.ptr(self.reward), _lib.ptr(self.done), self._stream()))
+        return self.obs, self.reward, self.done
+
+    # the Pensieve-style name BASELINE.json uses for the same call
+    get_video_chunk = step
+
+    def step_random(self, n_steps: int, seed: int, out=None, want_actions=True):
+        """n_steps fused decisions per lane under the built-in counter-based
+        random policy.  Returns dict(obs[n,OBS_DIM,N], reward[n,N], done[n,N], actions[n,N])."""
+        n = int(n_steps)
+        if out is None:
+            out = dict(
+                obs=torch.empty(n, OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device),
+                reward=torch.empty(n, self.n_lanes, dtype=torch.float32, device=self.device),
+                done=torch.empty(n, self.n_lanes, dtype=torch.uint8, device=self.device),
+                actions=(torch.empty(n, self.n_lanes, dtype=torch.int32, device=self.device)
+                         if want_actions else None))
+        _lib.check(self.lib.abr_env_step_random(
+            self._h, n, C.c_uint64(int(seed) & (2 ** 64 - 1)), _lib.ptr(out.get("obs")),
+            _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")), _lib.ptr(out.get("actions")),
+            self._stream()))
+        return out
+
+    # -- exact state -------------------------------------------------------
+    def observe_f64(self):
+        """dict of float64 [N] tensors: everything the reference's run() frame holds
+        at the call site (rows: _lib.F64_ROWS)."""
+        out = torch.empty(F64_DIM, self.n_lanes, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.abr_env_observe_f64(self._h, _lib.ptr(out), self._stream()))
+        return {k: out[i] for i, k in enumerate(F64_ROWS)}
+
+    def episode_qoe(self):
+        """calculate_qoe (Simulator.py:79-86) of each lane's (last) finished episode, float64 [N]."""
+        out = torch.empty(self.n_lanes, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.abr_env_episode_qoe(self._h, _lib.ptr(out), self._stream()))
+        return out
+
+    def state_view(self):
+        v = _lib.StateView()
+        _lib.check(self.lib.abr_env_get_state(self._h, C.byref(v)))
+        return v
+
+    def _view(self, addr, dtype, shape):
+        """Zero-copy tensor over a region of the workspace."""
+        off = addr - self.workspace.data_ptr()
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        return self.workspace[off:off + nbytes].view(dtype).view(*shape)
+
+    def history(self):
+        """(previous_bitrates u8[V,N], previous_bandwidths f64[V,N]) -- rows >= chunk_id are stale."""
+        v = self.state_view()
+        return (self._view(v.action_hist, torch.uint8, (self.video_length, self.n_lanes)),
+                self._view(v.bw_hist, torch.float64, (self.video_length, self.n_lanes)))
+
+    def mpc_inputs(self):
+        """Zero-copy float64/int32 tensors the MPC kernel reads and mutates (D9):
+        (chunk_id, last_bitrate, buffer_level, hist_n, hist_sum_inv, done)."""
+        v = self.state_view()
+        N = self.n_lanes
+        return (self._view(v.chunk_id, torch.int32, (N,)), self._view(v.last_bitrate, torch.int32, (N,)),
+                self._view(v.buffer_level, torch.float64, (N,)), self._view(v.hist_n, torch.float64, (N,)),
+                self._view(v.hist_sum_inv, torch.float64, (N,)), self._view(v.done, torch.uint8, (N,)))
+
+    # -- checkpoint / resume ------------------------------------------------
+    def state_dict(self):
+        """All simulator state is the workspace tensor (the reference keeps it in
+        run() locals and cannot checkpoint)."""
+        return dict(workspace=self.workspace.clone(), trace_id=self.trace_id, start_offset=self.start_offset)
+
+    def load_state_dict(self, sd):
+        if sd["workspace"].numel() != self.workspace.numel():
+            raise ValueError("workspace size mismatch: different config or lane count")
+        self.workspace.copy_(sd["workspace"])
+        self.trace_id, self.start_offset = sd["trace_id"], sd["start_offset"]
+
+
+def obs_dict(obs):
+    """Name the rows of an observation tensor."""
+    return {k: obs[..., i, :] for i, k in enumerate(OBS_ROWS)}

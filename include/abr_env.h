@@ -1,0 +1,234 @@
+/*
+ * abr_env.h -- C ABI of the MI355X-native batched ABR environment and MPC lookahead.
+ *
+ * This is the drop-in boundary for the one hot path BASELINE.json names: the
+ * tick loop of the reference's Simulator.run() (Simulator.py:135-208) and the
+ * exhaustive lookahead of its MPCBitrateController (mpc.py:120-186), vectorised
+ * over independent (trace, start-offset) lanes.
+ *
+ * The reference is pure Python with no FFI; its plugin boundary is inversion of
+ * control: run() calls abr_controller.get_next_bitrate(chunk_id,
+ * previous_bitrates, previous_bandwidths, buffer_level) once per chunk
+ * (Simulator.py:155).  This ABI turns that inside out: abr_env_reset() runs each
+ * lane up to its first get_next_bitrate() call site and hands back exactly the
+ * call's arguments as the observation; abr_env_step(actions) supplies the return
+ * value and runs to the next call site (or to simulation_end, Simulator.py:207).
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative ABR_E_* code; nothing
+ *    throws across the boundary.  abr_last_error() gives the message of the
+ *    calling thread's last failure.
+ *  - Every *_dev pointer is device memory owned by the CALLER (the data_ptr()
+ *    of a PyTorch-ROCm tensor).  The library allocates no device memory: its
+ *    per-lane state and lookup tables live in the caller-provided workspace.
+ *  - Work is only enqueued on the `stream` argument (a hipStream_t passed as
+ *    void*; NULL = the default stream).  No call synchronises, except
+ *    abr_env_create (one-time table upload).
+ *  - Re-entrant per handle, no globals.  Lane arrays are struct-of-arrays with
+ *    row stride n_lanes: field f of lane i is at base[f * n_lanes + i].
+ */
+#ifndef ABR_ENV_H
+#define ABR_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABR_ABI_VERSION 1
+#define ABR_MAX_RATES 16
+#define ABR_MAX_HORIZON 8
+
+/* error codes */
+#define ABR_OK 0
+#define ABR_E_INVALID (-1)      /* bad argument / config */
+#define ABR_E_WORKSPACE (-2)    /* workspace too small or misaligned */
+#define ABR_E_HIP (-3)          /* a HIP runtime call failed */
+#define ABR_E_UNSUPPORTED (-4)  /* valid in the reference, not built here (yet) */
+
+/* per-lane bits of done_out */
+#define ABR_DONE_EPISODE 0x1    /* chunk_id >= video_length  (Simulator.py:207-208) */
+#define ABR_DONE_TIMEOUT 0x2    /* hit config.max_ticks before finishing */
+#define ABR_DONE_BADACT 0x4     /* action outside [0, n_rates): lane frozen (the reference raises IndexError) */
+
+/* float32 observation rows written by reset/step: the four arguments of
+ * get_next_bitrate (Simulator.py:155) first, then run() locals at that instant */
+enum {
+    ABR_OBS_CHUNK_ID = 0,       /* chunk_id                                   */
+    ABR_OBS_LAST_BITRATE = 1,   /* previous_bitrates[-1] (index) or -1        */
+    ABR_OBS_LAST_BANDWIDTH = 2, /* previous_bandwidths[-1] or 0 (:164)        */
+    ABR_OBS_BUFFER_LEVEL = 3,   /* buffer_level [s]                           */
+    ABR_OBS_GLOBAL_TIME = 4,    /* global_time [s]                            */
+    ABR_OBS_PLAY_TIME = 5,      /* play_time [s]                              */
+    ABR_OBS_REBUFFER_TIME = 6,  /* rebuffer_time, cumulative [s]              */
+    ABR_OBS_STARTUP_TIME = 7,   /* start_up_time, cumulative [s]              */
+    ABR_OBS_DIM = 8
+};
+
+/* float64 rows of abr_env_observe_f64: everything the oracle records */
+enum {
+    ABR_F64_GLOBAL_TIME = 0, ABR_F64_REBUFFER_TIME, ABR_F64_STARTUP_TIME, ABR_F64_PLAY_TIME,
+    ABR_F64_AVERAGE_LATENCY, ABR_F64_BUFFER_LEVEL, ABR_F64_PLAY_LENGTH, ABR_F64_LAST_BANDWIDTH,
+    ABR_F64_CHUNK_ID, ABR_F64_PLAY_ID, ABR_F64_LAST_BITRATE, ABR_F64_FLAGS /* start_up | buffer_empty<<1 | buffer_full<<2 */,
+    ABR_F64_HIST_N, ABR_F64_HIST_SUM_INV, ABR_F64_TICK, ABR_F64_DOWNLOAD_TIME,
+    ABR_F64_DIM
+};
+
+/* Replaces: MPD (Simulator.py:11-17), QOEMetric (:19-24), NetworkInfo.interval
+ * (:39-42), the single-ladder Chunk that run() indexes (:82,156), and the
+ * constant a speed controller would return (:177; none ships, D8). */
+typedef struct abr_env_config {
+    int32_t n_rates;            /* len(mpd.chunks.bitrates), 1..ABR_MAX_RATES */
+    int32_t video_length;       /* mpd.video_length [chunks]                  */
+    double  chunk_length;       /* mpd.chunk_length [s]                       */
+    double  max_buffer;         /* mpd.max_buffer (compared in seconds, :190) */
+    double  start_up_length;    /* mpd.start_up_length [s]                    */
+    double  interval;           /* network_info.interval [s]                  */
+    double  rebuffer_weight;    /* qoe_metric.*                               */
+    double  variance_weight;
+    double  startup_weight;
+    double  latency_weight;
+    double  speed;              /* play_speed, constant                       */
+    double  ladder[ABR_MAX_RATES];
+    int32_t max_ticks;          /* per-episode bound on 0.01 s ticks; <=0: 32 * V * ceil(L/dt) */
+    int32_t auto_reset;         /* !=0: a lane that finishes is re-armed (same trace, same offset)
+                                   inside the step; the obs returned is the new episode's first */
+} abr_env_config;
+
+typedef struct abr_env abr_env;   /* opaque host-side handle */
+
+int  abr_abi_version(void);
+const char *abr_last_error(void);
+
+/* Bytes of device workspace (256-B aligned) abr_env_create needs for n_lanes. */
+int abr_env_workspace_bytes(const abr_env_config *cfg, int64_t n_lanes, size_t *bytes_out);
+
+/*
+ * Replaces Simulator.__init__/set_qoe_metric/set_network_info/set_mpd
+ * (Simulator.py:46-77).  traces_dev: all bandwidth traces back to back
+ * (float64, same unit as the ladder); trace t is traces_dev[trace_off_dev[t] ..
+ * + trace_len_dev[t]).  The three trace arrays must outlive the handle.
+ * Builds the universal tick tables on the host in float64 (the reference's
+ * global_time is lane-independent) and uploads them into the workspace.
+ */
+int abr_env_create(const abr_env_config *cfg, const double *traces_dev,
+                   const int64_t *trace_off_dev, const int32_t *trace_len_dev, int32_t n_traces,
+                   int64_t n_lanes, void *workspace_dev, size_t workspace_bytes, void *stream,
+                   abr_env **env_out);
+int abr_env_destroy(abr_env *env);
+
+/* When the lanes of this handle are a shard of a larger job: global id of lane 0,
+ * used only as the counter of the built-in random policy so that a sharded run
+ * reproduces the unsharded one.  Default 0. */
+int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
+
+/*
+ * run() state init (Simulator.py:95-133) plus the idle ticks up to the first
+ * get_next_bitrate call site.  Lane i uses trace trace_id_dev[i]; its
+ * bandwidths[idx] is trace[(start_offset_dev[i] + idx) % len] (D7: wrap is
+ * build-defined).  lane_mask_dev (nullable): only lanes with a non-zero byte
+ * are reset.  obs_out_dev: float32 [ABR_OBS_DIM][n_lanes] (nullable).
+ */
+int abr_env_reset(abr_env *env, const int32_t *trace_id_dev, const int32_t *start_offset_dev,
+                  const uint8_t *lane_mask_dev, float *obs_out_dev, void *stream);
+
+/*
+ * One chunk decision per lane: actions_dev[i] is what get_next_bitrate would
+ * have returned (Simulator.py:155); the lane then runs ticks T4..T9 and on,
+ * to its next call site or to simulation_end.  reward_out_dev[i] =
+ *   wr * d(rebuffer_time) + ws * d(start_up_time) + wv * |br[a] - br[a_prev]|
+ * (the per-step split of calculate_qoe, Simulator.py:79-86; the first step's
+ * deltas start from 0, so sum(reward) + wl * average_latency == run()'s return).
+ * Lanes already done are left untouched and report their done bits again.
+ */
+int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs_out_dev,
+                 float *reward_out_dev, uint8_t *done_out_dev, void *stream);
+
+/*
+ * n_steps fused decisions per lane with the built-in random policy
+ * action = philox4x32-10(key=seed, ctr=(lane, episode_step, episode_no, 0)) % n_rates.
+ * Outputs (all nullable) are [n_steps][...] slabs: obs [n_steps][ABR_OBS_DIM][n_lanes],
+ * reward/done/actions [n_steps][n_lanes].  Lanes progress independently (no
+ * per-step rendezvous), which is what removes the divergent-while-loop tail.
+ */
+int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed, float *obs_out_dev,
+                        float *reward_out_dev, uint8_t *done_out_dev, int32_t *actions_out_dev,
+                        void *stream);
+
+/* calculate_qoe (Simulator.py:79-86) in the reference's operation order from the
+ * lane's action history; meaningful for lanes whose episode is complete (with
+ * auto_reset: the last completed episode).  qoe_out_dev: float64 [n_lanes]. */
+int abr_env_episode_qoe(abr_env *env, double *qoe_out_dev, void *stream);
+
+/* Full float64 observation, [ABR_F64_DIM][n_lanes]. */
+int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream);
+
+/* Device pointers into the workspace for consumers that need exact float64
+ * state (the MPC adapter) or want to checkpoint it. */
+typedef struct abr_env_state_view {
+    int64_t n_lanes;
+    const int32_t *chunk_id;      /* [n_lanes] */
+    const int32_t *last_bitrate;  /* [n_lanes], -1 before the first chunk */
+    const double  *buffer_level;  /* [n_lanes] */
+    double        *hist_n;        /* [n_lanes] len(previous_bandwidths), as float64 */
+    double        *hist_sum_inv;  /* [n_lanes] sum(1/x for x in previous_bandwidths), list order */
+    const uint8_t *done;          /* [n_lanes] ABR_DONE_* bits */
+    const uint8_t *action_hist;   /* [video_length][n_lanes] previous_bitrates */
+    const double  *bw_hist;       /* [video_length][n_lanes] previous_bandwidths */
+} abr_env_state_view;
+int abr_env_get_state(abr_env *env, abr_env_state_view *view_out);
+
+/* ---------------------------------------------------------------------- */
+/* MPC lookahead                                                            */
+/* ---------------------------------------------------------------------- */
+
+/* Replaces what MPCBitrateController reads through the player protocol
+ * (mpc.py:56-57: get_mpd, get_qoe_metric) and its horizon (mpc.py:59). */
+typedef struct abr_mpc_config {
+    int32_t n_rates;            /* len(mpd.chunks[0].bitrates)  mpc.py:173 */
+    int32_t horizon;            /* 2..ABR_MAX_HORIZON (the reference crashes at 1, mpc.py:186) */
+    int32_t video_length;       /* len(mpd.chunks) */
+    int32_t clip_horizon;       /* !=0: H_eff = min(H, V - chunk) (D12; the reference raises IndexError) */
+    double  chunk_length;       /* mpd.chunk_length  mpc.py:108,117,151 */
+    double  max_buffer;         /* mpd.max_buffer    mpc.py:108 */
+    double  variance_weight;    /* qoe.*             mpc.py:158-160 */
+    double  rebuffer_weight;
+    double  startup_weight;     /* multiplies the hard-zero startup_delay (mpc.py:141) */
+} abr_mpc_config;
+
+/*
+ * MPCBitrateController.next_bitrate() (mpc.py:181-186) for n_lanes independent
+ * players: harmonic-mean prediction fed back H times (mpc.py:81-93), exhaustive
+ * evaluation of objective() (mpc.py:120-162) over all n_rates^horizon combos in
+ * scipy.optimize.brute's C order with first-minimum tie-break (mpc.py:178), and
+ * int(result[0]).
+ *  chunk_dev/prev_bitrate_dev/buffer_dev: chunk_info.chunk_number /
+ *      .previous_bitrate / .buffer_level (mpc.py:124,132,136)
+ *  hist_n_dev/hist_sum_inv_dev: IN-OUT summary of chunk_info.previous_bandwidths
+ *      (length and sum of reciprocals in list order); grown by H predictions
+ *      exactly as the reference mutates the caller's list (mpc.py:92, D9)
+ *  br_table_dev/sz_table_dev: [video_length][n_rates] mpd.chunks[i].bitrates/.sizes
+ *  action_out_dev int32 [n_lanes]; best_flat_out_dev (nullable) int32 [n_lanes]
+ *  flat arg-min index; best_J_out_dev (nullable) float64 [n_lanes];
+ *  lane_mask_dev (nullable): lanes with a zero byte are skipped entirely
+ *  (no history mutation, outputs untouched).
+ */
+int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
+                   const int32_t *prev_bitrate_dev, const double *buffer_dev, double *hist_n_dev,
+                   double *hist_sum_inv_dev, const double *br_table_dev, const double *sz_table_dev,
+                   const uint8_t *lane_mask_dev, int32_t *action_out_dev,
+                   int32_t *best_flat_out_dev, double *best_J_out_dev, int64_t n_lanes,
+                   void *stream);
+
+/* Diagnostic: the full objective grid of ONE lane, J_out_dev float64
+ * [n_rates^horizon], given explicit predictions pred_dev[horizon]. */
+int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk, int32_t prev_bitrate,
+                           double buffer_level, const double *pred_dev, const double *br_table_dev,
+                           const double *sz_table_dev, double *J_out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABR_ENV_H */

@@ -1,0 +1,156 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports
+every symbol include/abr_env.h declares, its structs match the ctypes mirrors,
+and argument validation fails with codes + messages (no GPU needed: these
+paths return before any HIP call)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+
+HDR = os.path.join(ROOT, "include", "abr_env.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from abrsimulator_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def _declared():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(abr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = _declared()
+    assert "abr_env_step" in names and "abr_mpc_select" in names and len(names) >= 14
+    lib = L.lib()
+    bound = {n for n, _, _ in L.SYMBOLS}
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in abr_env.h but not exported"
+        assert n in bound, f"{n} declared in abr_env.h but not bound in _lib.SYMBOLS"
+    assert lib.abr_abi_version() == 1
+
+
+def test_struct_layout_matches_header(L):
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "abr_env.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(abr_env_config), offsetof(abr_env_config, ladder),
+         offsetof(abr_env_config, max_ticks), offsetof(abr_env_config, speed),
+         offsetof(abr_env_config, interval));
+  printf("%zu %zu %zu\n", sizeof(abr_mpc_config), offsetof(abr_mpc_config, chunk_length),
+         offsetof(abr_mpc_config, startup_weight));
+  printf("%zu %zu\n", sizeof(abr_env_state_view), offsetof(abr_env_state_view, bw_hist));
+  printf("%d %d %d %d\n", ABR_OBS_DIM, ABR_F64_DIM, ABR_MAX_RATES, ABR_MAX_HORIZON);
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    a = list(map(int, out[0].split()))
+    E = L.EnvConfig
+    assert a == [C.sizeof(E), E.ladder.offset, E.max_ticks.offset, E.speed.offset, E.interval.offset]
+    b = list(map(int, out[1].split()))
+    M = L.MpcConfig
+    assert b == [C.sizeof(M), M.chunk_length.offset, M.startup_weight.offset]
+    c_ = list(map(int, out[2].split()))
+    assert c_ == [C.sizeof(L.StateView), L.StateView.bw_hist.offset]
+    assert list(map(int, out[3].split())) == [L.OBS_DIM, L.F64_DIM, L.MAX_RATES, L.MAX_HORIZON]
+    assert len(L.OBS_ROWS) == L.OBS_DIM and len(L.F64_ROWS) == L.F64_DIM
+
+
+def _cfg(L, **kw):
+    c = L.EnvConfig()
+    c.n_rates, c.video_length = 6, 48
+    c.chunk_length, c.max_buffer, c.start_up_length, c.interval = 4.0, 20.0, 8.0, 1.0
+    c.speed = 1.0
+    for i, b in enumerate([0.3, 0.75, 1.2, 1.85, 2.85, 4.3]):
+        c.ladder[i] = b
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_workspace_bytes_and_validation(L):
+    lib = L.lib()
+    n = C.c_size_t()
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 65536, C.byref(n)) == 0
+    per_lane = 4 * 8 + 8 + 15 * 4 + 2 + 48 + 48 * 8 + 4 * 8 + 48
+    assert n.value >= 65536 * per_lane and n.value < 65536 * per_lane + 32 * 2 ** 20
+    n2 = C.c_size_t()
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 131072, C.byref(n2)) == 0
+    assert n2.value - n.value == 65536 * per_lane      # linear in lanes, tables shared
+    for bad in (dict(n_rates=0), dict(n_rates=17), dict(video_length=0), dict(chunk_length=0.0),
+                dict(interval=-1.0), dict(max_buffer=0.0), dict(speed=0.0)):
+        rc = lib.abr_env_workspace_bytes(C.byref(_cfg(L, **bad)), 64, C.byref(n))
+        assert rc == -1, bad
+        assert len(lib.abr_last_error()) > 0
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 0, C.byref(n)) == -1
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, interval=1e-9)), 64, C.byref(n)) == -4
+    with pytest.raises(L.AbrError):
+        L.check(lib.abr_env_workspace_bytes(C.byref(_cfg(L, n_rates=99)), 64, C.byref(n)))
+
+
+def test_create_rejects_bad_workspace_before_touching_the_gpu(L):
+    lib = L.lib()
+    h = C.c_void_p()
+    one = C.c_void_p(256)
+    rc = lib.abr_env_create(C.byref(_cfg(L)), one, one, one, 1, 64, None, 0, None, C.byref(h))
+    assert rc == -2 and b"workspace" in lib.abr_last_error()
+    rc = lib.abr_env_create(C.byref(_cfg(L)), one, one, one, 1, 64, C.c_void_p(257), 1 << 30, None,
+                            C.byref(h))
+    assert rc == -2
+    rc = lib.abr_env_create(C.byref(_cfg(L)), one, one, one, 1, 64, C.c_void_p(512), 1024, None,
+                            C.byref(h))
+    assert rc == -2 and b"need" in lib.abr_last_error()
+    rc = lib.abr_env_create(C.byref(_cfg(L)), None, one, one, 1, 64, C.c_void_p(512), 1 << 30, None,
+                            C.byref(h))
+    assert rc == -1
+    assert lib.abr_env_step(None, one, None, None, None, None) == -1
+    assert lib.abr_env_reset(None, one, None, None, None, None) == -1
+
+
+def test_mpc_validation(L):
+    lib = L.lib()
+    m = L.MpcConfig()
+    m.n_rates, m.horizon, m.video_length = 6, 5, 48
+    one = C.c_void_p(256)
+    args = [one] * 7 + [None, one, None, None]
+    assert lib.abr_mpc_select(C.byref(m), *args, 0, None) == -1          # n_lanes < 1
+    m.horizon = 1                                                        # reference crashes (mpc.py:186)
+    assert lib.abr_mpc_select(C.byref(m), *args, 4, None) == -1
+    m.horizon, m.n_rates = 8, 16                                         # 16^8 > int32
+    assert lib.abr_mpc_select(C.byref(m), *args, 4, None) == -4
+    m.horizon, m.n_rates = 5, 6
+    assert lib.abr_mpc_select(C.byref(m), None, *args[1:], 4, None) == -1   # NULL pointer
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure; the product path must not reach it."""
+    pkg = os.path.join(ROOT, "abrsimulator_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_env_refuses_cpu_device(L):
+    import abrsimulator_amd as A
+    mpd = A.MPD(4, 4, 20, 8, A.Chunk([1.0, 2.0]))
+    with pytest.raises(ValueError):
+        A.BatchedABREnv(mpd, A.QOEMetric(1, 1, 1, 1), A.NetworkInfo(1.0, [1.0, 2.0]), 8, device="cpu")

@@ -1,0 +1,245 @@
+"""GPU parity of the env kernels (K1 step, K2 reset, K4 episode_qoe) through the C ABI.
+
+Bar: bit-exact float64 for every decision-feeding quantity and all clocks;
+average_latency within 1e-9 relative (it is carried as an exact integer sum of
+tick indices instead of the reference's per-tick multiply/divide recurrence --
+see csrc/abr_env.hip: lane_avg_latency; BASELINE.json's bar is 1e-5); float32
+observations equal float32(float64 golden).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ENV_GOLDENS, load_golden
+from helpers import F64_EXACT, make_env, philox_action
+
+pytestmark = pytest.mark.gpu
+
+LAT_RTOL = 1e-9
+
+
+def _cmp_step(f64, g, s, name):
+    for k in F64_EXACT:
+        got = f64[k].cpu().numpy()
+        assert np.array_equal(got, g[k][:, s]), (name, s, k, got[:4], g[k][:4, s])
+    lat = f64["average_latency"].cpu().numpy()
+    ref = g["average_latency"][:, s]
+    assert np.allclose(lat, ref, rtol=LAT_RTOL, atol=1e-12), (name, s, lat[:4], ref[:4])
+    assert np.array_equal(f64["chunk_id"].cpu().numpy().astype(np.int32), g["chunk_id"][:, s])
+    assert np.array_equal(f64["play_id"].cpu().numpy().astype(np.int32), g["play_id"][:, s])
+    assert np.array_equal(f64["last_bitrate"].cpu().numpy().astype(np.int32), g["arg_last_bitrate"][:, s])
+    assert np.array_equal(f64["last_bandwidth"].cpu().numpy(), g["arg_last_bandwidth"][:, s])
+    fl = f64["flags"].cpu().numpy().astype(np.int32)
+    assert np.array_equal(fl & 1, g["start_up"][:, s])
+    assert np.array_equal((fl >> 1) & 1, g["buffer_empty"][:, s])
+    assert np.array_equal((fl >> 2) & 1, g["buffer_full"][:, s])
+
+
+@pytest.mark.parametrize("name", ENV_GOLDENS)
+def test_step_matches_reference_goldens(name):
+    """Replays the golden actions step by step; compares the full float64
+    observation at EVERY call site with what the reference's run() frame held."""
+    m, g = load_golden(name)
+    N, V = g["actions"].shape
+    env = make_env(m, g["traces"], N)
+    obs = env.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
+    acts = torch.from_numpy(g["actions"]).cuda()
+    rew_sum = np.zeros(N)
+    for s in range(V):
+        _cmp_step(env.observe_f64(), g, s, name)
+        o = obs.cpu().numpy()
+        assert np.array_equal(o[3], g["buffer_level"][:, s].astype(np.float32))
+        assert np.array_equal(o[4], g["global_time"][:, s].astype(np.float32))
+        assert np.array_equal(o[2], g["arg_last_bandwidth"][:, s].astype(np.float32))
+        assert np.array_equal(o[0], g["chunk_id"][:, s].astype(np.float32))
+        obs, rew, done = env.step(acts[:, s].contiguous())
+        rew_sum += rew.double().cpu().numpy()
+        d = done.cpu().numpy()
+        assert (d == (1 if s == V - 1 else 0)).all(), (s, d)
+    # terminal state = the frame calculate_qoe was called from
+    f = env.observe_f64()
+    for k in ["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]:
+        assert np.array_equal(f[k].cpu().numpy(), g["final_" + k]), k
+    assert np.allclose(f["average_latency"].cpu().numpy(), g["final_average_latency"], rtol=LAT_RTOL)
+    assert np.array_equal(f["play_id"].cpu().numpy().astype(np.int32), g["final_play_id"])
+    # previous_bandwidths / previous_bitrates lists
+    ah, bh = env.history()
+    assert np.array_equal(bh.cpu().numpy().T, g["final_bandwidths"])
+    assert np.array_equal(ah.cpu().numpy().T.astype(np.int32), g["actions"])
+    # K4: calculate_qoe; and the per-step rewards add up to it
+    qoe = env.episode_qoe().cpu().numpy()
+    assert np.allclose(qoe, g["final_qoe"], rtol=1e-10, atol=1e-12)
+    wl = m["weights"][3]
+    assert np.allclose(rew_sum + wl * g["final_average_latency"], g["final_qoe"], rtol=2e-5, atol=1e-4)
+    # stepping a finished env is a no-op that reports done again
+    obs2, rew2, done2 = env.step(acts[:, 0].contiguous())
+    assert (done2.cpu().numpy() == 1).all() and (rew2.cpu().numpy() == 0).all()
+
+
+def _random_case(seed, N, V=12, L=4.0, interval=1.0, n_traces=7, ragged=False, max_buffer=20.0,
+                 start_up=8.0, bw=(0.2, 6.0), ladder=(0.3, 0.75, 1.2, 1.85, 2.85, 4.3)):
+    rng = np.random.default_rng(seed)
+    if ragged:
+        lens = rng.integers(300, 3001, n_traces)
+    else:
+        lens = np.full(n_traces, 1000)
+    traces = [rng.uniform(bw[0], bw[1], l).astype(np.float32).astype(np.float64) for l in lens]
+    meta = dict(ladder=list(ladder), chunk_length=L, video_length=V, max_buffer=max_buffer,
+                start_up_length=start_up, interval=interval, weights=[4.3, 1, 1, 0.1], speed=1.0)
+    trace_id = rng.integers(0, n_traces, N).astype(np.int32)
+    offset = np.array([rng.integers(0, lens[t]) for t in trace_id], np.int32)
+    actions = rng.integers(0, len(ladder), (N, V)).astype(np.int32)
+    return meta, traces, trace_id, offset, actions
+
+
+@pytest.mark.parametrize("case", [
+    dict(seed=1, N=1000), dict(seed=2, N=777, ragged=True), dict(seed=3, N=512, L=1.0, start_up=2.0),
+    dict(seed=4, N=300, interval=0.3, bw=(0.1, 1.5)), dict(seed=5, N=256, max_buffer=5.0, start_up=4.0),
+    dict(seed=6, N=1, V=3), dict(seed=7, N=65, L=2.5, interval=0.7, V=9)])
+def test_step_matches_oracle_seeded(oracle, case):
+    """Same seeded inputs through the HIP path and the C oracle (wrap-around of
+    short ragged traces included, where the reference itself would raise)."""
+    meta, traces, trace_id, offset, actions = _random_case(**case)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions)
+    N, V = actions.shape
+    env = make_env(meta, traces, N)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    acts = torch.from_numpy(actions).cuda()
+    for s in range(V):
+        f = env.observe_f64()
+        for k in F64_EXACT:
+            assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (s, k)
+        assert np.allclose(f["average_latency"].cpu().numpy(), steps["average_latency"][:, s],
+                           rtol=LAT_RTOL, atol=1e-12)
+        assert np.array_equal(f["last_bandwidth"].cpu().numpy(), steps["last_bandwidth"][:, s])
+        env.step(acts[:, s].contiguous())
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    assert np.array_equal(env.observe_f64()["global_time"].cpu().numpy(), fin["global_time"])
+
+
+def test_step_random_fused_equals_stepwise_and_oracle(oracle):
+    """The fused random-policy rollout (K1 in MODE 2) == step-by-step with the
+    same philox actions == the oracle replaying those actions."""
+    meta, traces, trace_id, offset, _ = _random_case(seed=11, N=640, V=10)
+    N, V, seed = 640, 10, 0x1234ABCD5678
+    env = make_env(meta, traces, N)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    out = env.step_random(V, seed)
+    acts = out["actions"].cpu().numpy()            # [V, N]
+    want = np.stack([philox_action(seed, np.arange(N), s, 0, 6) for s in range(V)])
+    assert np.array_equal(acts, want)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, acts.T.copy())
+    obs = out["obs"].cpu().numpy()                 # obs[s] = observation AFTER step s
+    for s in range(V - 1):
+        assert np.array_equal(obs[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32))
+        assert np.array_equal(obs[s, 4], steps["global_time"][:, s + 1].astype(np.float32))
+        assert np.array_equal(obs[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32))
+    assert (out["done"].cpu().numpy()[:-1] == 0).all() and (out["done"].cpu().numpy()[-1] == 1).all()
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    # step-by-step twin
+    env2 = make_env(meta, traces, N)
+    env2.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    for s in range(V):
+        o, r, d = env2.step(out["actions"][s].contiguous())
+        assert torch.equal(o, out["obs"][s]) and torch.equal(r, out["reward"][s])
+        assert torch.equal(d, out["done"][s])
+
+
+def test_auto_reset_and_lane_id_base(oracle):
+    """auto_reset re-arms finished lanes inside the step; a shard with
+    lane_id_base reproduces the matching slice of the unsharded run."""
+    meta, traces, trace_id, offset, _ = _random_case(seed=21, N=256, V=5)
+    N, V, seed = 256, 5, 99
+    env = make_env(meta, traces, N, auto_reset=True)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    out = env.step_random(2 * V + 2, seed)
+    done = out["done"].cpu().numpy()
+    assert (done[V - 1] == 1).all() and (done[2 * V - 1] == 1).all()
+    assert done.sum() == 2 * N
+    acts = out["actions"].cpu().numpy()
+    # episode 1 restarts from the same trace/offset with fresh philox counters
+    want1 = np.stack([philox_action(seed, np.arange(N), s, 1, 6) for s in range(V)])
+    assert np.array_equal(acts[V:2 * V], want1)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, want1.T.copy())
+    obs = out["obs"].cpu().numpy()
+    # obs returned with done is the new episode's first call site
+    assert np.array_equal(obs[V - 1, 4], steps["global_time"][:, 0].astype(np.float32))
+    assert np.array_equal(obs[V, 3], steps["buffer_level"][:, 1].astype(np.float32))
+    # after 2V steps the last finished episode is episode 1
+    env_b = make_env(meta, traces, N, auto_reset=True)
+    env_b.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    env_b.step_random(2 * V, seed)
+    assert np.allclose(env_b.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    # shard [100, 200) with lane_id_base = 100
+    sh = make_env(meta, traces, 100, lane_id_base=100)
+    sh.reset(torch.from_numpy(trace_id[100:200].copy()), torch.from_numpy(offset[100:200].copy()))
+    o2 = sh.step_random(V, seed)
+    assert torch.equal(o2["actions"], out["actions"][:V, 100:200])
+    assert torch.equal(o2["obs"][:V - 1], out["obs"][:V - 1, :, 100:200])
+
+
+def test_bad_action_and_masked_reset_and_checkpoint():
+    meta, traces, trace_id, offset, actions = _random_case(seed=31, N=128, V=6)
+    env = make_env(meta, traces, 128)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    a = torch.from_numpy(actions[:, 0].copy()).cuda()
+    a[5] = 6       # out of range: the reference would raise IndexError (Simulator.py:156)
+    a[7] = -1
+    o, r, d = env.step(a)
+    d = d.cpu().numpy()
+    assert d[5] == 4 and d[7] == 4 and (np.delete(d, [5, 7]) == 0).all()
+    # checkpoint, advance, restore, advance again -> identical
+    sd = env.state_dict()
+    a1 = torch.from_numpy(actions[:, 1].copy()).cuda()
+    o1 = env.step(a1)[0].clone()
+    env.load_state_dict(sd)
+    o2 = env.step(a1)[0].clone()
+    assert torch.equal(o1, o2)
+    # masked reset only touches the chosen lanes
+    mask = torch.zeros(128, dtype=torch.uint8); mask[5] = 1; mask[7] = 1
+    before = env.observe_f64()["tick"].clone()
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset), mask=mask)
+    after = env.observe_f64()["tick"]
+    assert after[5] == 401 and after[7] == 401
+    keep = torch.ones(128, dtype=torch.bool); keep[5] = False; keep[7] = False
+    assert torch.equal(before[keep.cuda()], after[keep.cuda()])
+
+
+def test_full_size_properties():
+    """BASELINE.json size (65 536 lanes): properties that need no oracle run."""
+    N, V = 65536, 48
+    rng = np.random.default_rng(0)
+    traces = [rng.uniform(0.2, 6.0, 1000).astype(np.float32).astype(np.float64) for _ in range(1024)]
+    meta = dict(ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=V,
+                max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1], speed=1.0)
+    env = make_env(meta, traces, N)
+    tid = torch.arange(N, dtype=torch.int32) % 1024
+    off = torch.from_numpy(rng.integers(0, 1000, N).astype(np.int32))
+    env.reset(tid, off)
+    out = env.step_random(V, 7)
+    obs = out["obs"]
+    done = out["done"]
+    assert int(done[-1].sum()) == N and int(done[:-1].sum()) == 0
+    # clocks are monotone, chunk ids count up by one, buffer within [0, max_buffer + L]
+    assert bool((obs[1:, 4] >= obs[:-1, 4])[: V - 2].all())
+    assert torch.equal(obs[: V - 1, 0], torch.arange(1, V, device="cuda", dtype=torch.float32)[:, None].expand(V - 1, N))
+    assert float(obs[:, 3].min()) >= 0.0 and float(obs[:, 3].max()) <= 24.0
+    # live-stream gating: chunk c cannot start before (c+1) * L
+    t = obs[: V - 1, 4]
+    lower = (torch.arange(1, V, device="cuda", dtype=torch.float32)[:, None] + 1) * 4.0
+    assert bool((t >= lower - 1e-3).all())
+    # two lanes with identical (trace, offset, lane id) inputs agree: determinism across launches
+    env2 = make_env(meta, traces, N)
+    env2.reset(tid, off)
+    out2 = env2.step_random(V, 7)
+    assert torch.equal(out2["obs"], obs) and torch.equal(out2["reward"], out["reward"])
+    # QoE identity: sum(reward) + wl * average_latency == calculate_qoe
+    q = env.episode_qoe()
+    lat = env.observe_f64()["average_latency"]
+    assert torch.allclose(out["reward"].double().sum(0) + 0.1 * lat, q, rtol=2e-5, atol=1e-3)
