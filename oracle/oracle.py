@@ -159,6 +159,14 @@ def mpc_predict_list(horizon, hist):
     return pred, h[:n.value]
 
 
+def mpc_predict_ns(horizon, n, S):
+    """(n, S)-form predictor: returns (pred[H], n_after, S_after)."""
+    cn, cs = C.c_double(float(n)), C.c_double(float(S))
+    pred = np.zeros(horizon, np.float64)
+    lib().oracle_mpc_predict_ns(C.c_int32(horizon), C.byref(cn), C.byref(cs), _p(pred, C.c_double))
+    return pred, cn.value, cs.value
+
+
 def mpc_brute(cfg, br, sz, chunk, prev, buf, pred, want_J=True):
     br = np.ascontiguousarray(br, np.float64)
     sz = np.ascontiguousarray(sz, np.float64)

@@ -123,9 +123,7 @@ def test_horizon_clip_and_mask(oracle):
     a = ctl.next_bitrate(want_details=True).cpu().numpy()
     for i in range(N - 1):
         he = min(H, V - chunk[i])
-        hn_o, hs_o = hn[i:i + 1].copy(), hs[i:i + 1].copy()
-        pred = np.zeros(H)
-        oracle.lib().oracle_mpc_predict_ns(H, hn_o.ctypes.data, hs_o.ctypes.data, pred.ctypes.data)
+        pred, _, _ = oracle.mpc_predict_ns(H, hn[i], hs[i])
         if he >= 2:
             cfg = oracle.mpc_cfg(B, he, V, L, mb, 1.0, 4.3, 0.0)
             f, Jm, _ = oracle.mpc_brute(cfg, br, sz, chunk[i], prev[i], buf[i], pred[:he])
@@ -188,10 +186,7 @@ def test_mpc_drives_env_rollout(oracle):
             if c == 0:
                 return 0
             he = min(H, V - c)
-            hn = np.array([state["n"]]); hs = np.array([state["s"]])
-            pred = np.zeros(H)
-            oracle.lib().oracle_mpc_predict_ns(H, hn.ctypes.data, hs.ctypes.data, pred.ctypes.data)
-            state["n"], state["s"] = float(hn[0]), float(hs[0])      # D9
+            pred, state["n"], state["s"] = oracle.mpc_predict_ns(H, state["n"], state["s"])   # D9
             if he >= 2:
                 mcfg = oracle.mpc_cfg(6, he, V, L, 20.0, 1.0, 4.3, 0.0)
                 f, _, _ = oracle.mpc_brute(mcfg, br, sz, c, int(obs["last_bitrate"]),

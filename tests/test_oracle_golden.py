@@ -110,3 +110,22 @@ def test_mpc_sweep_bit_exact(oracle, name):
                                       g["buf"][i], g["pred"][i])
         assert np.array_equal(J, g["Jfull"][i])
         assert f == g["flat"][i]
+
+
+@pytest.mark.parametrize("name", ["env_bench_shape", "env_starved_i03", "env_speed125", "env_l3_i07"])
+def test_pure_python_restatement_bit_exact(name):
+    """oracle/pyloop.py (the interpreter-baseline twin) against the same fixtures."""
+    from oracle.pyloop import PyTickEnv, run_episode
+    m, g = load_golden(name)
+    for i in range(0, g["actions"].shape[0], 5):
+        env = PyTickEnv(m["ladder"], m["chunk_length"], m["video_length"], m["max_buffer"],
+                        m["start_up_length"], m["interval"], m["weights"],
+                        g["traces"][g["trace_id"][i]], int(g["offset"][i]), m["speed"])
+        obs, qoe = run_episode(env, [int(a) for a in g["actions"][i]])
+        assert qoe == g["final_qoe"][i]
+        for s, o in enumerate(obs):
+            for k in ["global_time", "rebuffer_time", "start_up_time", "play_time",
+                      "average_latency", "buffer_level"]:
+                assert o[k] == g[k][i, s], (i, s, k)
+            assert o["last_bandwidth"] == g["arg_last_bandwidth"][i, s]
+        assert env.t == g["final_global_time"][i]
