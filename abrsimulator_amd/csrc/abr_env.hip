@@ -60,6 +60,7 @@ struct EnvParams {
     int32_t n_rates, video_length, max_ticks, auto_reset;
     int32_t play_ticks_per_chunk;  // P: first n with n-fold sum of speed*dt >= chunk_length (:185)
     int32_t n_intervals;           // entries in interval_tick minus sentinel
+    int32_t t_block;               // ticks per block of the tick loop (<= shortest interval)
     double chunk_length, max_buffer, start_up_length;
     double wr, wv, ws, wl;
     double sd;                     // speed * dt, the product the reference forms each tick (:182)
@@ -77,7 +78,7 @@ struct EnvParams {
     // per-lane state, SoA (device, in the workspace)
     double *buf, *last_bw, *hist_n, *hist_s;
     long long *sumk;               // sum of tick indices of playing ticks (latency integral)
-    int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *plen, *play_id, *j, *tpos, *trace_id, *offset0;
+    int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *j, *tpos, *trace_id, *offset0;
     int32_t *last_action, *n_su_obs, *n_rb_obs, *episode_no;
     uint8_t *flags, *done;
     uint8_t *action_hist;          // [V][n_lanes]
@@ -114,35 +115,65 @@ __host__ __device__ inline uint32_t philox_action(uint64_t seed, uint64_t lane, 
 // ---------------------------------------------------------------------------
 // K1/K2: the tick loop
 // ---------------------------------------------------------------------------
-// A lane in registers.  "Call site" = the instant inside tick k at which the
-// reference calls abr_controller.get_next_bitrate (Simulator.py:155): T1-T3 of
-// tick k are done, the download is not paused and download_time == 0.
+// "Call site" = the instant inside tick k at which the reference calls
+// abr_controller.get_next_bitrate (Simulator.py:155): T1-T3 of tick k are done,
+// the download is not paused and download_time == 0.  A step runs from one call
+// site to the next and has two phases:
+//   A  downloading: every tick adds bandwidth*dt until downloaded_size >= target.
+//      The download cannot pause inside phase A: buffer_full only turns on in a
+//      tick that completes a chunk (buffer_level grows nowhere else, :170), and
+//      availability is monotone in time.
+//   B  waiting for the next call site: chunk available (:143) and not buffer_full.
+//
+// Kernel structure (one lane per thread, one wave per workgroup):
+//   block loop   every T ticks (T <= the shortest trace interval, so a lane
+//                crosses at most one interval boundary per block):
+//                - SERVICE lanes that reached a step boundary in the last block:
+//                  finish the chunk record (one float64 division), emit
+//                  reward/obs/done, take the next action (fused mode) or retire;
+//                - PREFETCH bandwidth*dt of the current and next interval and the
+//                  boundary tick, so that
+//   tick loop    is straight-line predicated VALU code with no memory access and
+//                no divergent branch: ~40 vector instructions per tick per wave.
+//                `__any(running)` ends it early when the whole wave is waiting.
+// Lanes that hit their boundary mid-block idle until the block ends (T/2 ticks
+// on average, against ~400 ticks per step).
 struct Lane {
-    double buf, dl, target, c;     // buffer_level, downloaded_size, target_size, bandwidth*dt
+    double buf, dl, target, c, c_next;   // buffer_level, downloaded_size, target_size, bandwidth*dt
     long long sumk;
-    int32_t k, chunk_id, n_su, n_rb, n_play, plen, play_id, j, tpos, n_dl;
-    int32_t avail_k, k_end, tlen, cur_action, last_action;
-    bool su, be, bf;               // start_up, buffer_empty, buffer_full
-    bool dlact, playing;           // !download_pause, !play_pause of the current tick
+    int32_t k, k_end, chunk_id, n_su, n_rb, n_play, n_dl, j, tpos, tlen;
+    int32_t avail_k, avail_next, cur_action, last_action;
+    bool su, be, bf;        // start_up, buffer_empty, buffer_full
+    bool done_dl;           // phase B
+    bool running;           // ticking inside the current block
     const double *trace;
 };
+
+// T1-T3 of tick s.k (Simulator.py:137-149 with R2/R3); sets running = not at a call site
+__device__ inline void lane_head(Lane &s) {
+    s.n_su += s.su ? 1 : 0;
+    s.n_rb += (!s.su && s.be) ? 1 : 0;
+    const bool call = s.done_dl && (s.k >= s.avail_k) && !s.bf;
+    s.running = !call;
+}
 
 __device__ inline void lane_init(Lane &s, const EnvParams &p, int32_t offset0) {
     // Simulator.py:95-130
     s.buf = 0.0; s.dl = 0.0; s.target = 0.0; s.sumk = 0;
-    s.k = 0; s.chunk_id = 0; s.n_su = 0; s.n_rb = 0; s.n_play = 0; s.plen = 0; s.play_id = 0;
-    s.n_dl = 0; s.cur_action = -1; s.last_action = -1;
+    s.k = 0; s.chunk_id = 0; s.n_su = 0; s.n_rb = 0; s.n_play = 0; s.n_dl = 0;
+    s.cur_action = -1; s.last_action = -1;
     s.su = true; s.be = true; s.bf = false;
-    s.dlact = false; s.playing = false;
-    // bandwidth index of tick 0 is int(0.0 / interval) = 0
-    s.j = 0;
+    s.done_dl = true;                  // nothing is downloading: wait for the first call site
+    s.j = 0;                           // int(0.0 / interval) == 0
     s.tpos = offset0 % s.tlen;
     s.avail_k = p.avail_tick[0];
+    s.avail_next = s.avail_k;
+    lane_head(s);                      // T1-T3 of tick 0
 }
 
-// (re)load the per-interval constants: bandwidth*dt of interval j and the tick
-// at which interval j ends.  Advances j while k has passed the end (robust for
-// intervals shorter than a tick).
+// Per-block refresh of the interval constants.  Moves j/tpos forward while k has
+// passed the interval end (also covers intervals shorter than one tick), then
+// loads bandwidth*dt for the current and the next interval.
 __device__ inline void lane_refresh_interval(Lane &s, const EnvParams &p) {
     int32_t ke = p.interval_tick[s.j + 1];
     while (s.k >= ke) {
@@ -151,50 +182,9 @@ __device__ inline void lane_refresh_interval(Lane &s, const EnvParams &p) {
         ke = p.interval_tick[s.j + 1];
     }
     s.k_end = ke;
-    s.c = s.trace[s.tpos] * kDt;   // bandwidth * dt  (:160; the product is formed first)
-}
-
-// T1-T3 of tick k (Simulator.py:137-149 with R2/R3)
-__device__ inline void tick_head(Lane &s) {
-    s.n_su += s.su ? 1 : 0;
-    s.n_rb += (!s.su && s.be) ? 1 : 0;
-    s.dlact = (s.k >= s.avail_k) && !s.bf;   // available_id >= chunk_id and not buffer_full
-    s.playing = !(s.be || s.su);
-}
-
-// T4-T9 of tick k (Simulator.py:152-208).  Returns kTickCompleted when a chunk
-// finished downloading in this tick, | kTickEnded when the episode ended.
-constexpr int kTickCompleted = 1, kTickEnded = 2;
-__device__ inline int tick_tail(Lane &s, const EnvParams &p, int64_t lane, double &bw_done) {
-    int ev = 0;
-    if (s.dlact) {
-        s.dl = s.dl + s.c;                                   // :160
-        s.n_dl++;                                            // :161 (download_time == G[n_dl])
-        if (s.dl >= s.target) {                              // :163
-            bw_done = s.dl / p.G[s.n_dl];                    // :164
-            p.bw_hist[(int64_t)s.chunk_id * p.n_lanes + lane] = bw_done;
-            p.action_hist[(int64_t)s.chunk_id * p.n_lanes + lane] = (uint8_t)s.cur_action;  // :165
-            s.last_action = s.cur_action;
-            s.chunk_id++;                                    // :166
-            s.dl = 0.0; s.n_dl = 0;                          // :167-168
-            s.buf += p.chunk_length;                         // :170
-            s.avail_k = p.avail_tick[s.chunk_id];
-            ev = kTickCompleted;
-        }
-    }
-    if (s.playing) {                                         // :174-187
-        s.sumk += s.k;                                       // latency integral, see lane_avg_latency
-        s.n_play++;
-        s.plen++;
-        s.buf -= p.sd;                                       // :184
-        if (s.plen == p.play_ticks_per_chunk) { s.plen = 0; s.play_id++; }   // :185-187
-    }
-    s.bf = (s.buf >= p.max_buffer);                          // :190-193
-    if (s.buf <= 0.0) { s.buf = 0.0; s.be = true; } else s.be = false;       // :194-198
-    if (s.su && s.buf >= p.start_up_length) s.su = false;    // :201-202
-    s.k++;                                                   // :205
-    if (s.chunk_id >= p.video_length) ev |= kTickEnded;      // :207-208
-    return ev;
+    const int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+    s.c = s.trace[s.tpos] * kDt;       // bandwidth * dt  (:160; the product is formed first)
+    s.c_next = s.trace[tn] * kDt;
 }
 
 // average_latency (Simulator.py:179-180).  The reference's recurrence telescopes
@@ -213,20 +203,20 @@ __device__ inline double lane_avg_latency(const EnvParams &p, long long sumk, in
 __device__ inline void lane_load(Lane &s, const EnvParams &p, int64_t i) {
     s.buf = p.buf[i]; s.sumk = p.sumk[i];
     s.k = p.k[i]; s.chunk_id = p.chunk_id[i]; s.n_su = p.n_su[i]; s.n_rb = p.n_rb[i];
-    s.n_play = p.n_play[i]; s.plen = p.plen[i]; s.play_id = p.play_id[i];
-    s.j = p.j[i]; s.tpos = p.tpos[i];
+    s.n_play = p.n_play[i]; s.j = p.j[i]; s.tpos = p.tpos[i];
     s.last_action = p.last_action[i]; s.cur_action = -1;
-    uint8_t f = p.flags[i];
+    const uint8_t f = p.flags[i];
     s.su = f & kFlagStartUp; s.be = f & kFlagBufEmpty; s.bf = f & kFlagBufFull;
-    s.dl = 0.0; s.n_dl = 0; s.target = 0.0;
-    s.avail_k = p.avail_tick[s.chunk_id < p.video_length ? s.chunk_id : p.video_length];
+    s.dl = 0.0; s.n_dl = 0; s.target = 0.0; s.done_dl = true; s.running = false;
+    const int32_t c = s.chunk_id < p.video_length ? s.chunk_id : p.video_length;
+    s.avail_k = p.avail_tick[c];
+    s.avail_next = s.avail_k;
 }
 
 __device__ inline void lane_store(const Lane &s, const EnvParams &p, int64_t i) {
     p.buf[i] = s.buf; p.sumk[i] = s.sumk;
     p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
-    p.n_play[i] = s.n_play; p.plen[i] = s.plen; p.play_id[i] = s.play_id;
-    p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
+    p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
                            (s.bf ? kFlagBufFull : 0));
 }
@@ -248,16 +238,6 @@ __device__ inline void write_obs(const Lane &s, const EnvParams &p, int64_t i, f
 // MODE 0: reset (fresh lanes run to their first call site)
 // MODE 1: step  (one externally supplied action per lane)
 // MODE 2: fused random-policy rollout of n_steps decisions per lane
-//
-// One wave = 64 lanes, one lane per thread.  Loop nest:
-//   outer trip  = one trace interval (bandwidth constant): per-lane loads of
-//                 bandwidth and the interval's end tick happen here, together
-//                 for the whole wave, so the tick loop itself has no loads on
-//                 its critical path;
-//   inner trip  = one 0.01 s tick of every lane still running (exec-masked).
-// Interval ends are universal ticks, so after its first (partial) interval a
-// wave's lanes cross interval boundaries in lockstep.  Lanes retire from the
-// wave as their step finishes; `__any` (s_cbranch on the ballot) ends the loops.
 template <int MODE>
 __global__ __launch_bounds__(64) void env_advance_kernel(
     EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
@@ -271,43 +251,99 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
     bool active = in_range;       // still has work in this launch
     bool touched = in_range;      // state must be written back
     bool fresh = (MODE == 0);     // running a new episode up to its first call site
-    bool at_call = false;         // needs an action before its next tick
+    bool need_action = false;     // at a call site, waiting for the block loop to hand it an action
     uint8_t done = 0;
     int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0, prev_action = -1;
     double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
     int32_t step_idx = 0;
+    s.running = false; s.done_dl = true;
 
     if (in_range) {
         if (MODE == 0) {
             if (lane_mask && !lane_mask[i]) { active = false; touched = false; }
             if (active) {
-                int32_t t = trace_id_in[i];
+                const int32_t t = trace_id_in[i];
                 offset0 = offset_in ? offset_in[i] : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
                 lane_init(s, p, offset0);
-                tick_head(s);            // T1-T3 of tick 0
             }
         } else {
             done = p.done[i];
-            int32_t t = p.trace_id[i];
+            const int32_t t = p.trace_id[i];
             offset0 = p.offset0[i];
             s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
             lane_load(s, p, i);
             n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
             last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
             if (done) active = false;
-            // a live lane sits at a call site: download not paused, playing as the flags say
-            s.dlact = true; s.playing = !(s.be || s.su);
-            at_call = active;
+            need_action = active;        // a live lane sits at a call site
         }
     }
 
+    const double L = p.chunk_length, sd = p.sd, max_buffer = p.max_buffer, sul = p.start_up_length;
+    const int32_t V = p.video_length, max_ticks = p.max_ticks, T = p.t_block;
+
     while (__any(active)) {
-        if (active) lane_refresh_interval(s, p);
-        bool run = active;
-        while (__any(run)) {
-            if (run && at_call) {
+        // ================= SERVICE: lanes at a step boundary =================
+        if (active && !s.running) {
+            const bool ended = s.chunk_id >= V;
+            const bool timeout = !ended && (s.k >= max_ticks);
+            bool emit_obs = !need_action;      // need_action: nothing happened yet in this launch
+            if (!need_action && !fresh) {
+                const int64_t o = (int64_t)step_idx * p.n_lanes + i;
+                double var = 0.0;
+                if (s.done_dl && s.cur_action >= 0) {
+                    // the chunk this step downloaded (:164-165)
+                    const double bw = s.dl / p.G[s.n_dl];
+                    const int64_t h = (int64_t)(s.chunk_id - 1) * p.n_lanes + i;
+                    p.bw_hist[h] = bw;
+                    p.action_hist[h] = (uint8_t)s.cur_action;
+                    last_bw = bw;
+                    hist_s = hist_s + 1.0 / bw;        // sum(1/x), list order (mpc.py:86-88)
+                    hist_n = hist_n + 1.0;
+                    s.last_action = s.cur_action;
+                    if (prev_action >= 0) var = fabs(p.ladder[s.cur_action] - p.ladder[prev_action]);
+                }
+                // per-step split of calculate_qoe (Simulator.py:83-85)
+                const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
+                                 p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
+                if (ended) done |= ABR_DONE_EPISODE;
+                if (timeout) done |= ABR_DONE_TIMEOUT;
+                if (reward_out) reward_out[o] = (float)r;
+                if (done_out) done_out[o] = done;
+                n_su_obs = s.n_su; n_rb_obs = s.n_rb;
+                s.cur_action = -1;
+                if (ended || timeout) {
+                    p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
+                    p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                    p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
+                    if (p.auto_reset && ended) {
+                        // re-arm: this step's obs is the new episode's first call site
+                        for (int c = 0; c < V; c++)
+                            p.ep_actions[(int64_t)c * p.n_lanes + i] =
+                                p.action_hist[(int64_t)c * p.n_lanes + i];
+                        lane_init(s, p, offset0);
+                        episode_no++;
+                        n_su_obs = 0; n_rb_obs = 0;
+                        last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                        done = 0; fresh = true;
+                        emit_obs = !s.running;     // already at a call site only if avail_tick[0] == 0
+                    }
+                }
+            } else if (!need_action && fresh && timeout) {
+                done |= ABR_DONE_TIMEOUT;
+                if (MODE != 0 && done_out) done_out[(int64_t)step_idx * p.n_lanes + i] = done;
+            }
+            if (emit_obs) {
+                fresh = false;
+                float *obs = obs_out ? obs_out + (int64_t)step_idx * ABR_OBS_DIM * p.n_lanes : nullptr;
+                write_obs(s, p, i, obs, last_bw);
+                step_idx++;
+                if (done || step_idx >= n_total) active = false;
+                else need_action = true;       // fused: take the next action right away
+            }
+            if (active && need_action) {
                 // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
                 int32_t a;
                 if (MODE == 1) a = actions[i];
@@ -315,78 +351,81 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                                                 (uint32_t)s.chunk_id, (uint32_t)episode_no,
                                                 (uint32_t)p.n_rates);
                 if (MODE == 2 && actions_out) actions_out[(int64_t)step_idx * p.n_lanes + i] = a;
+                need_action = false;
                 if (a < 0 || a >= p.n_rates) {
-                    done |= ABR_DONE_BADACT; active = false; run = false;
+                    done |= ABR_DONE_BADACT;
+                    if (done_out) done_out[(int64_t)step_idx * p.n_lanes + i] = done;
+                    if (reward_out) reward_out[(int64_t)step_idx * p.n_lanes + i] = 0.0f;
+                    float *obs = obs_out ? obs_out + (int64_t)step_idx * ABR_OBS_DIM * p.n_lanes : nullptr;
+                    write_obs(s, p, i, obs, last_bw);
+                    step_idx++;
+                    active = false;
                 } else {
                     prev_action = s.last_action;
                     s.cur_action = a;
-                    s.target = p.ladder[a] * p.chunk_length;        // :156
-                    at_call = false;
+                    s.target = p.ladder[a] * L;                      // :156
+                    s.dl = 0.0; s.n_dl = 0; s.done_dl = false;
+                    s.avail_next = p.avail_tick[s.chunk_id + 1];
+                    s.running = true;          // T4 of this very tick comes next
                 }
             }
-            if (run) {
-                double bw_done = 0.0;
-                const int ev = tick_tail(s, p, i, bw_done);
-                if (ev & kTickCompleted) {               // previous_bandwidths.append (:164)
-                    last_bw = bw_done;
-                    hist_s = hist_s + 1.0 / bw_done;     // sum(1/x), list order (mpc.py:86-88)
-                    hist_n = hist_n + 1.0;
-                }
-                const bool ended = ev & kTickEnded;
-                const bool timeout = !ended && (s.k >= p.max_ticks);
-                if (!(ended || timeout)) tick_head(s);   // T1-T3 of the next tick
-                const bool call = !(ended || timeout) && s.dlact && (s.n_dl == 0);
-                if (ended || timeout || call) {
-                    // ---- step boundary ----
-                    const int64_t o = (int64_t)step_idx * p.n_lanes + i;
-                    bool emit_obs = true;
-                    if (!fresh) {
-                        // per-step split of calculate_qoe (Simulator.py:83-85)
-                        // every boundary but a timeout follows exactly one completed chunk
-                        const double var = (prev_action >= 0 && !timeout)
-                                         ? fabs(p.ladder[s.last_action] - p.ladder[prev_action]) : 0.0;
-                        const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
-                                         p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
-                        if (ended) done |= ABR_DONE_EPISODE;
-                        if (timeout) done |= ABR_DONE_TIMEOUT;
-                        if (reward_out) reward_out[o] = (float)r;
-                        if (done_out) done_out[o] = done;
-                        n_su_obs = s.n_su; n_rb_obs = s.n_rb;
-                        if (ended || timeout) {
-                            p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
-                            p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
-                            p.ep_qoe_terms[2 * p.n_lanes + i] =
-                                lane_avg_latency(p, s.sumk, s.n_play);
-                            if (p.auto_reset && ended) {
-                                // re-arm: the step's obs is the new episode's first call site
-                                for (int c = 0; c < p.video_length; c++)
-                                    p.ep_actions[(int64_t)c * p.n_lanes + i] =
-                                        p.action_hist[(int64_t)c * p.n_lanes + i];
-                                lane_init(s, p, offset0);
-                                lane_refresh_interval(s, p);
-                                tick_head(s);
-                                episode_no++;
-                                n_su_obs = 0; n_rb_obs = 0;
-                                last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
-                                done = 0; fresh = true; emit_obs = false;
-                            }
-                        }
-                    } else if (timeout) {
-                        done |= ABR_DONE_TIMEOUT;
-                        if (MODE != 0 && done_out) done_out[o] = done;
-                    }
-                    if (emit_obs) {
-                        fresh = false;
-                        float *obs = obs_out ? obs_out + (int64_t)step_idx * ABR_OBS_DIM * p.n_lanes
-                                             : nullptr;
-                        write_obs(s, p, i, obs, last_bw);
-                        step_idx++;
-                        if (done || step_idx >= n_total) { active = false; run = false; }
-                        else at_call = true;         // fused: take the next action right away
-                    }
-                }
-                if (run && s.k >= s.k_end) run = false;  // interval over: back to the outer loop
-            }
+        }
+        if (!__any(active)) break;
+        // ================= PREFETCH interval constants =================
+        if (active) lane_refresh_interval(s, p);
+
+        // ================= TICK LOOP: predicated, no memory, no divergence =================
+        double buf = s.buf, dl = s.dl, c = s.c;
+        const double target = s.target, c_next = s.c_next;
+        int32_t k = s.k, k_end = s.k_end, chunk_id = s.chunk_id, n_su = s.n_su, n_rb = s.n_rb;
+        int32_t n_play = s.n_play, n_dl = s.n_dl, avail_k = s.avail_k;
+        const int32_t avail_next = s.avail_next;
+        uint32_t sk = 0;
+        bool su = s.su, be = s.be, bf = s.bf, done_dl = s.done_dl;
+        bool running = active && s.running;
+        bool crossed = false;
+        for (int32_t t = 0; t < T; t++) {
+            if (!__any(running)) break;
+            // ---- T4 download (Simulator.py:152-170) ----
+            const bool dling = running && !done_dl;
+            const double dl2 = dl + c;                               // :160
+            dl = dling ? dl2 : dl;
+            n_dl += dling ? 1 : 0;                                   // :161
+            const bool hit = dling && (dl2 >= target);               // :163
+            done_dl = done_dl || hit;
+            chunk_id += hit ? 1 : 0;                                 // :166
+            avail_k = hit ? avail_next : avail_k;
+            const double bufA = hit ? buf + L : buf;                 // :170
+            // ---- T5 playback (:174-187) ----
+            const bool playing = running && !(be || su);
+            sk += playing ? (uint32_t)k : 0u;                        // latency integral
+            n_play += playing ? 1 : 0;
+            const double bufB = playing ? bufA - sd : bufA;          // :184
+            // ---- T6 buffer flags (:190-198) ----
+            bf = bufB >= max_buffer;
+            be = bufB <= 0.0;
+            buf = be ? 0.0 : bufB;
+            // ---- T7 start-up exit (:201-202) ----
+            su = su && !(buf >= sul);
+            // ---- T8/T9 clock, termination (:205-208) ----
+            k += running ? 1 : 0;
+            const bool next = running && (chunk_id < V) && (k < max_ticks);
+            // ---- T1-T3 of the next tick (:137-149) ----
+            n_su += (next && su) ? 1 : 0;
+            n_rb += (next && !su && be) ? 1 : 0;
+            const bool call = done_dl && (k >= avail_k) && !bf;
+            running = next && !call;
+            // ---- bandwidth of the next tick's interval (:158-159) ----
+            const bool cross = (k == k_end);
+            c = cross ? c_next : c;
+            crossed = crossed || cross;
+        }
+        if (active) {
+            s.buf = buf; s.dl = dl; s.c = c; s.k = k; s.chunk_id = chunk_id; s.n_su = n_su;
+            s.n_rb = n_rb; s.n_play = n_play; s.n_dl = n_dl; s.avail_k = avail_k;
+            s.su = su; s.be = be; s.bf = bf; s.done_dl = done_dl; s.running = running;
+            s.sumk += (long long)sk;
+            (void)crossed;   // j/tpos catch up in lane_refresh_interval
         }
     }
 
@@ -435,10 +474,11 @@ __global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
     out[ABR_F64_PLAY_TIME * n + i] = p.GP[p.n_play[i]];
     out[ABR_F64_AVERAGE_LATENCY * n + i] = lane_avg_latency(p, p.sumk[i], p.n_play[i]);
     out[ABR_F64_BUFFER_LEVEL * n + i] = p.buf[i];
-    out[ABR_F64_PLAY_LENGTH * n + i] = p.GP[p.plen[i]];
+    // play_length restarts from 0 every P playing ticks (:185-187); play_id counts the restarts
+    out[ABR_F64_PLAY_LENGTH * n + i] = p.GP[p.n_play[i] % p.play_ticks_per_chunk];
     out[ABR_F64_LAST_BANDWIDTH * n + i] = p.last_bw[i];
     out[ABR_F64_CHUNK_ID * n + i] = (double)p.chunk_id[i];
-    out[ABR_F64_PLAY_ID * n + i] = (double)p.play_id[i];
+    out[ABR_F64_PLAY_ID * n + i] = (double)(p.n_play[i] / p.play_ticks_per_chunk);
     out[ABR_F64_LAST_BITRATE * n + i] = (double)p.last_action[i];
     out[ABR_F64_FLAGS * n + i] = (double)p.flags[i];
     out[ABR_F64_HIST_N * n + i] = p.hist_n[i];
@@ -503,7 +543,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
     L->f64_state = o; o = align_up(o + sizeof(double) * 4 * N, A);
     L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);
-    L->i32_state = o; o = align_up(o + sizeof(int32_t) * 15 * N, A);
+    L->i32_state = o; o = align_up(o + sizeof(int32_t) * 13 * N, A);
     L->u8_state = o; o = align_up(o + 2 * N, A);
     L->action_hist = o; o = align_up(o + V * N, A);
     L->bw_hist = o; o = align_up(o + sizeof(double) * V * N, A);
@@ -558,6 +598,13 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
             while (jcur <= idx && jcur < L.n_intervals + 2) itick[jcur++] = k;
         }
     }
+    // ticks per block of the tick loop: at most one interval boundary per block
+    int32_t t_block = 128;
+    for (size_t jj = 0; jj + 1 < itick.size() && itick[jj + 1] != INT_MAX; jj++) {
+        int32_t len = itick[jj + 1] - itick[jj];
+        if (len < t_block) t_block = len;
+    }
+    if (t_block < 1) t_block = 1;
     std::vector<int32_t> atick((size_t)cfg->video_length + 2, INT_MAX);
     {
         int64_t ccur = 0;
@@ -580,6 +627,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     EnvParams &p = e->p;
     p.n_rates = cfg->n_rates; p.video_length = cfg->video_length; p.max_ticks = mt;
     p.auto_reset = cfg->auto_reset; p.play_ticks_per_chunk = P; p.n_intervals = L.n_intervals;
+    p.t_block = t_block;
     p.chunk_length = cfg->chunk_length; p.max_buffer = cfg->max_buffer;
     p.start_up_length = cfg->start_up_length;
     p.wr = cfg->rebuffer_weight; p.wv = cfg->variance_weight; p.ws = cfg->startup_weight;
@@ -597,9 +645,9 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     p.sumk = (long long *)(w + L.i64_state);
     int32_t *q = (int32_t *)(w + L.i32_state);
     p.k = q; p.chunk_id = q + N; p.n_su = q + 2 * N; p.n_rb = q + 3 * N; p.n_play = q + 4 * N;
-    p.plen = q + 5 * N; p.play_id = q + 6 * N; p.j = q + 7 * N; p.tpos = q + 8 * N;
-    p.trace_id = q + 9 * N; p.offset0 = q + 10 * N; p.last_action = q + 11 * N;
-    p.n_su_obs = q + 12 * N; p.n_rb_obs = q + 13 * N; p.episode_no = q + 14 * N;
+    p.j = q + 5 * N; p.tpos = q + 6 * N; p.trace_id = q + 7 * N; p.offset0 = q + 8 * N;
+    p.last_action = q + 9 * N; p.n_su_obs = q + 10 * N; p.n_rb_obs = q + 11 * N;
+    p.episode_no = q + 12 * N;
     uint8_t *u = (uint8_t *)(w + L.u8_state);
     p.flags = u; p.done = u + N;
     p.action_hist = (uint8_t *)(w + L.action_hist);

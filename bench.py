@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workloads (config.workload in the JSON line)
+  env_random  (default; BASELINE.json configs[1]) 65 536 lanes per GPU, built-in
+              random-bitrate policy, 1 024 synthetic 1 000-pt traces.  A "step" is one
+              chunk decision for every lane; `--fuse F` decisions share one kernel launch.
+              metric = env-steps/s = lanes * K / time.
+  mpc         (configs[2], MPC half) 65 536 lanes x MPC horizon 5 over 6 rates:
+              a step is one abr_mpc_select over all lanes; metric = combos/s.
+  env_mpc     (configs[2]) MPC-driven rollout: every step = mpc_select + env step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying
+`roofline` (dominant kernel, HIP-event timed inside the timed region) and
+`cpu_baseline` (the C oracle on the host cores, bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
+V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, 20.0, 8.0, 1.0
+WEIGHTS = [4.3, 1.0, 1.0, 0.1]
+N_TRACES, TRACE_LEN = 1024, 1000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 GHz
+
+# per-lane state bytes one launch reads and writes back (csrc/abr_env.hip: lane_load/lane_store
+# + the scalars around them): 4 f64 + 1 i64 + 13 i32 + 2 u8
+STATE_BYTES = 4 * 8 + 8 + 13 * 4 + 2
+
+
+def synth_traces(mixed=False):
+    rng = np.random.default_rng(0)
+    if mixed:
+        lens = rng.integers(300, 3001, N_TRACES)
+    else:
+        lens = np.full(N_TRACES, TRACE_LEN)
+    return [rng.uniform(0.2, 6.0, int(n)).astype(np.float32).astype(np.float64) for n in lens]
+
+
+def lane_assignment(lane0, n, traces):
+    i = np.arange(lane0, lane0 + n, dtype=np.uint64)
+    tid = (i % np.uint64(len(traces))).astype(np.int32)
+    lens = np.array([len(t) for t in traces], np.uint64)
+    off = ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % lens[tid]).astype(np.int32)
+    return tid, off
+
+
+def cpu_baseline_env(traces, seed, budget_s=12.0):
+    """The C oracle (oracle/abr_oracle.c) on every host core: same traces, same
+    lane->trace map, same philox actions as the GPU run; a bounded lane sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    cfg = O.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, INTERVAL, WEIGHTS, 1.0)
+
+    def prep(lane0, n):
+        tid, off = lane_assignment(lane0, n, traces)
+        acts = np.stack([O.philox_action(seed, np.arange(lane0, lane0 + n), s, 0, len(LADDER))
+                         for s in range(V)], 1).astype(np.int32)
+        return tid, off, acts
+
+    def run(inp):
+        t0 = time.perf_counter()
+        O.env_batch(cfg, traces, *inp)
+        return time.perf_counter() - t0
+
+    probe = run(prep(0, 256))                             # ~40 ms on one core
+    per_core = max(256, int(256 * (budget_s / max(probe, 1e-4)) // 256 * 256))
+    per_core = min(per_core, 16384)
+    inputs = [prep(c * per_core, per_core) for c in range(cores)]   # untimed
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:                 # ctypes releases the GIL
+        list(ex.map(run, inputs))
+    wall = time.perf_counter() - t0
+    n_steps = cores * per_core * V
+    out = dict(value=n_steps / wall, unit="env-steps/s", cores=cores, kind="port",
+               sample=f"{cores * per_core} lanes x {V}-chunk episodes ({n_steps} env-steps) of the "
+                      f"same workload, C oracle -O2 -ffp-contract=off, one thread per core, "
+                      f"{wall:.1f} s wall")
+    # like-for-like interpreter figure (the reference is CPython): one core, a few lanes
+    from oracle.pyloop import PyTickEnv, run_episode
+    tid, off = lane_assignment(0, 16, traces)
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(16):
+        e = PyTickEnv(LADDER, L, V, MAX_BUFFER, START_UP, INTERVAL, WEIGHTS, traces[tid[i]], int(off[i]))
+        acts = [int(O.philox_action(seed, np.array([i]), s, 0, len(LADDER))[0]) for s in range(V)]
+        run_episode(e, acts)
+        done += V
+        if time.perf_counter() - t0 > 8.0:
+            break
+    out["python_loop"] = dict(value=done / (time.perf_counter() - t0), unit="env-steps/s", cores=1,
+                              sample=f"{done} env-steps, pure-CPython tick loop (oracle/pyloop.py)")
+    return out
+
+
+def cpu_baseline_mpc(budget_s=10.0):
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    mc = O.mpc_cfg(len(LADDER), 5, V, L, MAX_BUFFER, 1.0, 4.3, 0.0)
+    br = np.tile(np.array(LADDER), (V, 1))
+    sz = br * L
+    rng = np.random.default_rng(1)
+
+    def run(n):
+        t0 = time.perf_counter()
+        O.mpc_select(mc, br, sz, rng.integers(0, V - 5, n), rng.integers(0, 6, n),
+                     rng.uniform(0, MAX_BUFFER, n), np.full(n, 5.0), 5.0 / rng.uniform(0.5, 5, n))
+        return time.perf_counter() - t0
+
+    probe = run(64)
+    per_core = int(min(65536, max(64, 64 * budget_s / max(probe, 1e-4))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda c: run(per_core), range(cores)))
+    wall = time.perf_counter() - t0
+    combos = cores * per_core * 6 ** 5
+    return dict(value=combos / wall, unit="combos/s", cores=cores, kind="port",
+                sample=f"{cores * per_core} lane decisions x 7776 combos, C oracle (literal "
+                       f"objective per combo, no prefix sharing), {wall:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=960)
+    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--fuse", type=int, default=16, help="chunk decisions per kernel launch")
+    ap.add_argument("--lanes-per-gpu", type=int, default=65536)
+    ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
+    ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import abrsimulator_amd as A
+    from abrsimulator_amd._lib import OBS_DIM
+
+    N = a.lanes_per_gpu
+    traces = synth_traces(a.mixed_traces)
+    lane0 = rank * N
+    tid, off = lane_assignment(lane0, N, traces)
+    mpd = A.MPD(V, L, MAX_BUFFER, START_UP, A.Chunk(LADDER))
+    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
+                          auto_reset=True, lane_id_base=lane0)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    K, W = a.steps, a.warmup
+    ev = []
+    extra = {}
+
+    if a.workload == "env_random":
+        F = max(1, min(a.fuse, K))
+        bufs = [dict(obs=torch.empty(F, OBS_DIM, N, dtype=torch.float32, device=dev),
+                     reward=torch.empty(F, N, dtype=torch.float32, device=dev),
+                     done=torch.empty(F, N, dtype=torch.uint8, device=dev), actions=None)
+                for _ in range(2)]
+        gather = world > 1 and not a.no_gather
+        if gather:
+            # the one collective of the path: all-gather of (obs, reward), overlapped with the
+            # next launch on a side stream (double-buffered slabs)
+            comm = torch.cuda.Stream(dev)
+            g_obs = [torch.empty(world, F, OBS_DIM, N, dtype=torch.float32, device=dev) for _ in range(2)]
+            g_rew = [torch.empty(world, F, N, dtype=torch.float32, device=dev) for _ in range(2)]
+            pending = [None, None]
+
+        def run(n_steps, timed):
+            left, it = n_steps, 0
+            while left > 0:
+                f = min(F, left)
+                b = it & 1
+                if gather and pending[b] is not None:
+                    torch.cuda.current_stream(dev).wait_event(pending[b])   # slab b is free again
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                env.step_random(f, a.seed, out=bufs[b] if f == F else None)
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    ev.append((e0, e1, f))
+                if gather and f == F:
+                    done_ev = torch.cuda.Event(); done_ev.record()
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(done_ev)
+                        dist.all_gather_into_tensor(g_obs[b], bufs[b]["obs"])
+                        dist.all_gather_into_tensor(g_rew[b], bufs[b]["reward"])
+                        fin = torch.cuda.Event(); fin.record()
+                    pending[b] = fin
+                left -= f
+                it += 1
+            if gather:
+                torch.cuda.current_stream(dev).wait_stream(comm)
+
+        units_per_step = N * world
+        unit, metric = "env-steps/s", "env_steps_per_sec"
+    else:
+        player = A.EnvPlayer(env, mpd=A.MPD(V, L, MAX_BUFFER, START_UP,
+                                            [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
+                             qoe=A.QOEMetric(4.3, 1.0, 0.0))
+        ctl = A.BatchedMPCController(player, horizon=5, clip_horizon=True, device=dev)
+        # give every lane a history first (the reference divides by zero on an empty one, D13)
+        env.step_random(3, a.seed)
+        hist_n0, hist_s0 = player.hist_n.clone(), player.hist_sum_inv.clone()
+
+        def run(n_steps, timed):
+            for _ in range(n_steps):
+                if a.workload == "mpc":
+                    player.hist_n.copy_(hist_n0); player.hist_sum_inv.copy_(hist_s0)
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                act = ctl.next_bitrate()
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    ev.append((e0, e1, 1))
+                if a.workload == "env_mpc":
+                    env.step(torch.clamp(act, min=0))
+
+        if a.workload == "mpc":
+            units_per_step = N * world * 6 ** 5
+            unit, metric = "combos/s", "mpc_combos_per_sec"
+        else:
+            units_per_step = N * world
+            unit, metric = "env-steps/s", "env_steps_per_sec_mpc_policy"
+
+    run(W, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(K, True)
+    barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    kern_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+    avg_launch_s = float(np.mean(kern_ms)) * 1e-3
+    f_per_launch = float(np.mean([f for _, _, f in ev]))
+    if a.workload == "env_random":
+        # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
+        # launch; per decision: obs 32 + reward 4 + done 1 out, previous_bitrates 1 +
+        # previous_bandwidths 8 appended, and the trace points walked (8 B bandwidth + 4 B
+        # interval-end tick each; 407 ticks/decision at interval 1 s -> 4.07 points).
+        pts = 4.07 * (8 + 4)
+        per_decision = 32 + 4 + 1 + 1 + 8 + pts
+        alg_bytes = N * (2 * STATE_BYTES + f_per_launch * per_decision)
+        roof = dict(bound="hbm", kernel="env_advance_kernel<2>",
+                    achieved=alg_bytes / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                    traffic=None, avg_launch_us=avg_launch_s * 1e6,
+                    algorithmic_bytes_per_launch=alg_bytes,
+                    note="tick-exact semantics make this kernel VALU/latency-bound, not HBM-bound "
+                         "(SURVEY.md 8d); the HBM fraction is reported as mandated")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    else:
+        # K3 is fp64-VALU-bound: 99 flop per combo in the reference's formulation
+        flops = N * 6 ** 5 * 99.0
+        roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5>",
+                    achieved=flops / avg_launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                    traffic=None, avg_launch_us=avg_launch_s * 1e6,
+                    note="99 fp64 flop/combo on the 7 776-combo basis; prefix sharing executes fewer")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tj):
+        try:
+            t = json.load(open(tj)).get(a.workload)
+            if t and t.get("fuse") == (a.fuse if a.workload == "env_random" else 1) \
+                    and t.get("lanes") == N:
+                roof["traffic"] = t["bytes_per_launch"]
+                roof["traffic_source"] = t.get("source")
+        except Exception:
+            pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(traces, a.seed)
+
+    if rank == 0:
+        total_units = units_per_step * K
+        line = {
+            "metric": metric, "value": total_units / elapsed, "unit": unit, "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
+                       "fuse": a.fuse if a.workload == "env_random" else 1,
+                       "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
+                       "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
+                       "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
+                       "auto_reset": True,
+                       "collective": ("all_gather(obs,reward)" if world > 1 and not a.no_gather
+                                      and a.workload == "env_random" else "none")},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
