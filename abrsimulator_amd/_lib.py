@@ -63,6 +63,7 @@ SYMBOLS = [
                                  C.c_size_t, _P, C.POINTER(_P)]),
     ("abr_env_destroy", C.c_int, [_P]),
     ("abr_env_set_lane_id_base", C.c_int, [_P, C.c_int64]),
+    ("abr_env_set_impl", C.c_int, [_P, C.c_int32]),
     ("abr_env_reset", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step_random", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
@@ -86,8 +87,9 @@ def build(force=False):
     """Compile csrc/abr_env.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(CSRC, "abr_env.hip")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "abr_env.h")
+    deps = [src, hdr, os.path.join(CSRC, "abr_exact_jump.h")]
     stale = (not os.path.exists(SO_PATH)
-             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(d) for d in deps))
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-s", "-B", "libabr_hip.so"])
     return SO_PATH

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "abr_env.h"
+#include "abr_exact_jump.h"
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -91,6 +92,7 @@ struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
+    int impl;   // 0 = event-driven kernels (default), 1 = tick-by-tick kernels (cross-check)
 };
 
 // ---------------------------------------------------------------------------
@@ -449,6 +451,293 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1/K2, event-driven form: the same tick semantics without visiting every tick
+// ---------------------------------------------------------------------------
+// A step (call site -> next call site) is a handful of runs in which one
+// float64 variable receives the same constant every tick:
+//   phase A  downloaded_size += bandwidth*dt, one run per trace interval, until it
+//            reaches target_size at tick k_hit (abrx::chain<STOP_GE>);
+//            meanwhile buffer_level -= speed*dt while playing, until 0 (STOP_LE);
+//   hit tick buffer_level = (buffer_level + L) - speed*dt, flags, start-up exit;
+//   phase B  wait for availability: buffer_level drains for avail_tick - k ticks,
+//            then until buffer_level < max_buffer if buffer_full gates the download
+//            (STOP_LT).
+// abrx::chain executes each run in O(binades crossed) while producing the
+// bit-identical float64 value of the tick-by-tick loop (abr_exact_jump.h), and the
+// integer counters (ticks in start-up / rebuffering / playing, the latency
+// integral sum of k over playing ticks) have exact closed forms over a run.
+// State between the pieces is always "post-head": T1-T3 of tick s.k are done.
+struct LaneJ {
+    double buf;
+    long long sumk;
+    int32_t k, chunk_id, n_su, n_rb, n_play, j, tpos, tlen, avail_k, last_action;
+    bool su, be, bf;
+    const double *trace;
+};
+
+// m full iterations (T4-T9 of a tick without a completion, then T1-T3 of the next)
+__device__ inline void lanej_idle(LaneJ &s, const EnvParams &p, int32_t m) {
+    if (m <= 0) return;
+    if (s.su) {
+        s.n_su += m;                                   // :137-138, buffer untouched
+    } else if (s.be) {
+        s.n_rb += m;                                   // :139-140, buffer stays 0
+    } else {
+        int32_t a = 0;
+        double b = s.buf;
+        const bool zero = abrx::chain<abrx::STOP_LE>(b, -p.sd, 0.0, m, a);     // :184,:194
+        s.n_play += a;
+        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
+        if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
+        s.buf = b;
+        s.bf = b >= p.max_buffer;                      // :190, as of the last tick executed
+    }
+    s.k += m;
+}
+
+// From a post-head state that is not downloading: advance to the next call site
+// (returns true) or to max_ticks (returns false).
+__device__ inline bool lanej_wait_call(LaneJ &s, const EnvParams &p) {
+    const int32_t mt = p.max_ticks;
+    if (s.k >= s.avail_k && !s.bf) return true;
+    int32_t w = s.avail_k - s.k;
+    if (w < 0) w = 0;
+    if (w > mt - s.k) w = mt - s.k;
+    lanej_idle(s, p, w);
+    if (s.k >= mt) return false;
+    if (s.bf) {
+        // buffer_full gates the next download (:144): drain until buffer_level < max_buffer
+        if (s.su || s.be) {
+            // nothing drains the buffer: the reference spins forever; run out the clock
+            if (s.su) s.n_su += mt - s.k; else s.n_rb += mt - s.k;
+            s.k = mt;
+            return false;
+        }
+        int32_t a = 0;
+        double b = s.buf;
+        const bool cleared = abrx::chain<abrx::STOP_LT>(b, -p.sd, p.max_buffer, mt - s.k, a);
+        s.n_play += a;
+        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
+        s.k += a;
+        s.be = b <= 0.0;
+        if (s.be) { b = 0.0; s.n_rb += 1; }
+        s.buf = b;
+        s.bf = !cleared;
+        if (!cleared) return false;
+    }
+    return s.k < mt || (s.k >= s.avail_k && !s.bf);
+}
+
+__device__ inline void lanej_init(LaneJ &s, const EnvParams &p, int32_t offset0) {
+    // Simulator.py:95-130, then T1-T3 of tick 0
+    s.buf = 0.0; s.sumk = 0;
+    s.k = 0; s.chunk_id = 0; s.n_su = 1; s.n_rb = 0; s.n_play = 0;
+    s.last_action = -1;
+    s.su = true; s.be = true; s.bf = false;
+    s.j = 0; s.tpos = offset0 % s.tlen;
+    s.avail_k = p.avail_tick[0];
+}
+
+__device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
+    s.buf = p.buf[i]; s.sumk = p.sumk[i];
+    s.k = p.k[i]; s.chunk_id = p.chunk_id[i]; s.n_su = p.n_su[i]; s.n_rb = p.n_rb[i];
+    s.n_play = p.n_play[i]; s.j = p.j[i]; s.tpos = p.tpos[i];
+    s.last_action = p.last_action[i];
+    const uint8_t f = p.flags[i];
+    s.su = f & kFlagStartUp; s.be = f & kFlagBufEmpty; s.bf = f & kFlagBufFull;
+    const int32_t c = s.chunk_id < p.video_length ? s.chunk_id : p.video_length;
+    s.avail_k = p.avail_tick[c];
+}
+
+__device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i) {
+    p.buf[i] = s.buf; p.sumk[i] = s.sumk;
+    p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
+    p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
+    p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
+                           (s.bf ? kFlagBufFull : 0));
+}
+
+__device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i, float *obs,
+                                   double last_bw) {
+    if (!obs) return;
+    const int64_t n = p.n_lanes;
+    obs[ABR_OBS_CHUNK_ID * n + i] = (float)s.chunk_id;
+    obs[ABR_OBS_LAST_BITRATE * n + i] = (float)s.last_action;
+    obs[ABR_OBS_LAST_BANDWIDTH * n + i] = (float)last_bw;
+    obs[ABR_OBS_BUFFER_LEVEL * n + i] = (float)s.buf;
+    obs[ABR_OBS_GLOBAL_TIME * n + i] = (float)p.G[s.k];
+    obs[ABR_OBS_PLAY_TIME * n + i] = (float)p.GP[s.n_play];
+    obs[ABR_OBS_REBUFFER_TIME * n + i] = (float)p.G[s.n_rb];
+    obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void env_jump_kernel(
+    EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
+    const int32_t *__restrict__ offset_in, const uint8_t *__restrict__ lane_mask,
+    float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
+    int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < p.n_lanes;
+    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    const int32_t V = p.video_length, mt = p.max_ticks;
+    const double L = p.chunk_length;
+    LaneJ s;
+    bool active = in_range, touched = in_range;
+    uint8_t done = 0;
+    int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
+
+    if (in_range) {
+        if (MODE == 0) {
+            if (lane_mask && !lane_mask[i]) { active = false; touched = false; }
+            if (active) {
+                const int32_t t = trace_id_in[i];
+                offset0 = offset_in ? offset_in[i] : 0;
+                p.trace_id[i] = t; p.offset0[i] = offset0;
+                s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+                lanej_init(s, p, offset0);
+                if (!lanej_wait_call(s, p)) done |= ABR_DONE_TIMEOUT;
+                write_obs_j(s, p, i, obs_out, 0.0);
+            }
+        } else {
+            done = p.done[i];
+            const int32_t t = p.trace_id[i];
+            offset0 = p.offset0[i];
+            s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+            lanej_load(s, p, i);
+            n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
+            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+            if (done) active = false;
+        }
+    }
+
+    if (MODE != 0) {
+        for (int32_t step = 0; step < n_total; step++) {
+            const int64_t o = (int64_t)step * p.n_lanes + i;
+            float *obs = obs_out ? obs_out + (int64_t)step * ABR_OBS_DIM * p.n_lanes : nullptr;
+            if (active) {
+                // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
+                int32_t a;
+                if (MODE == 1) a = actions[i];
+                else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i),
+                                                (uint32_t)s.chunk_id, (uint32_t)episode_no,
+                                                (uint32_t)p.n_rates);
+                if (MODE == 2 && actions_out) actions_out[o] = a;
+                if (a < 0 || a >= p.n_rates) {
+                    done |= ABR_DONE_BADACT;
+                    if (reward_out) reward_out[o] = 0.0f;
+                    if (done_out) done_out[o] = done;
+                    write_obs_j(s, p, i, obs, last_bw);
+                    active = false;
+                } else {
+                    const double target = p.ladder[a] * L;                   // :156
+                    // ---- phase A: downloaded_size over the trace intervals ----
+                    // catch j/tpos up with k (phase B moved k only)
+                    int32_t ke = p.interval_tick[s.j + 1];
+                    while (s.k >= ke) {
+                        s.j++;
+                        s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+                        ke = p.interval_tick[s.j + 1];
+                    }
+                    double bw = s.trace[s.tpos];
+                    const int32_t lim = mt - s.k;
+                    double dl = 0.0;
+                    int32_t n_dl = 0, kk = s.k;
+                    bool hit = false;
+                    while (!hit && n_dl < lim) {
+                        // prefetch the next interval while this one is integrated
+                        const int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+                        const double bw_next = s.trace[tn];
+                        const int32_t ke_next = p.interval_tick[s.j + 2];
+                        int32_t n = ke - kk;
+                        if (n > lim - n_dl) n = lim - n_dl;
+                        int32_t adds = 0;
+                        hit = abrx::chain<abrx::STOP_GE>(dl, bw * kDt, target, n, adds);   // :160-163
+                        n_dl += adds; kk += adds;
+                        if (!hit && kk >= ke) { s.j++; s.tpos = tn; bw = bw_next; ke = ke_next; }
+                    }
+                    // ---- buffer side of the ticks before the completing one ----
+                    lanej_idle(s, p, hit ? n_dl - 1 : n_dl);
+                    bool ended = false, timeout = !hit;
+                    double var = 0.0;
+                    if (hit) {
+                        // ---- the completing tick (:163-170, then :174-202) ----
+                        const bool playing = !(s.be || s.su);
+                        double b = s.buf + L;                                  // :170
+                        if (playing) { s.sumk += s.k; s.n_play++; b = b - p.sd; }   // :184
+                        s.bf = b >= p.max_buffer;
+                        s.be = b <= 0.0;
+                        if (s.be) b = 0.0;
+                        s.buf = b;
+                        s.su = s.su && !(b >= p.start_up_length);              // :201-202
+                        s.k++;
+                        const double bwm = dl / p.G[n_dl];                     // :164
+                        const int64_t h = (int64_t)s.chunk_id * p.n_lanes + i;
+                        p.bw_hist[h] = bwm;
+                        p.action_hist[h] = (uint8_t)a;                         // :165
+                        last_bw = bwm;
+                        hist_s = hist_s + 1.0 / bwm;    // sum(1/x), list order (mpc.py:86-88)
+                        hist_n = hist_n + 1.0;
+                        if (s.last_action >= 0) var = fabs(p.ladder[a] - p.ladder[s.last_action]);
+                        s.last_action = a;
+                        s.chunk_id++;                                          // :166
+                        s.avail_k = p.avail_tick[s.chunk_id];
+                        ended = s.chunk_id >= V;                               // :207-208
+                        timeout = !ended && s.k >= mt;
+                        if (!ended && !timeout) {
+                            s.n_su += s.su ? 1 : 0;                            // T1 of the next tick
+                            s.n_rb += (!s.su && s.be) ? 1 : 0;
+                            timeout = !lanej_wait_call(s, p);                  // phase B
+                        }
+                    }
+                    // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
+                    const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
+                                     p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
+                    if (ended) done |= ABR_DONE_EPISODE;
+                    if (timeout) done |= ABR_DONE_TIMEOUT;
+                    if (reward_out) reward_out[o] = (float)r;
+                    if (done_out) done_out[o] = done;
+                    n_su_obs = s.n_su; n_rb_obs = s.n_rb;
+                    if (ended || timeout) {
+                        p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
+                        p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                        p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
+                        if (p.auto_reset && ended) {
+                            // re-arm: this step's obs is the new episode's first call site
+                            for (int c = 0; c < V; c++)
+                                p.ep_actions[(int64_t)c * p.n_lanes + i] =
+                                    p.action_hist[(int64_t)c * p.n_lanes + i];
+                            lanej_init(s, p, offset0);
+                            episode_no++;
+                            n_su_obs = 0; n_rb_obs = 0;
+                            last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                            done = 0;
+                            if (!lanej_wait_call(s, p)) done |= ABR_DONE_TIMEOUT;
+                        }
+                    }
+                    write_obs_j(s, p, i, obs, last_bw);
+                    if (done) active = false;
+                }
+            } else if (in_range) {
+                // lanes already finished report their terminal record again
+                if (reward_out) reward_out[o] = 0.0f;
+                if (done_out) done_out[o] = done;
+                if (MODE == 2 && actions_out) actions_out[o] = -1;
+                write_obs_j(s, p, i, obs, last_bw);
+            }
+        }
+    }
+
+    if (touched) {
+        lanej_store(s, p, i);
+        p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
+        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+        p.done[i] = done;
+    }
+}
+
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -676,6 +965,14 @@ extern "C" int abr_env_destroy(abr_env *env) {
     return ABR_OK;
 }
 
+// 0 = event-driven kernels (default), 1 = tick-by-tick kernels (kept as a cross-check)
+extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (impl != 0 && impl != 1) return fail(ABR_E_INVALID, "impl must be 0 (jump) or 1 (tick)");
+    env->impl = impl;
+    return ABR_OK;
+}
+
 // lane id base for the counter-based policy when lanes are a shard of a bigger job
 extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
@@ -690,7 +987,7 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
                              float *obs_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!trace_id_dev) return fail(ABR_E_INVALID, "trace_id_dev is NULL");
-    hipLaunchKernelGGL(env_advance_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+    hipLaunchKernelGGL(env->impl ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, nullptr, trace_id_dev, start_offset_dev,
                        lane_mask_dev, obs_out_dev, nullptr, nullptr, nullptr, 0, 0ull);
     HIP_TRY(hipGetLastError());
@@ -701,7 +998,7 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
                             float *reward_out_dev, uint8_t *done_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
-    hipLaunchKernelGGL(env_advance_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+    hipLaunchKernelGGL(env->impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
                        obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull);
     HIP_TRY(hipGetLastError());
@@ -713,7 +1010,7 @@ extern "C" int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed,
                                    uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
-    hipLaunchKernelGGL(env_advance_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+    hipLaunchKernelGGL(env->impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
                        obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
     HIP_TRY(hipGetLastError());

@@ -39,7 +39,7 @@ class BatchedABREnv:
 
     def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
                  device="cuda", speed: float = 1.0, auto_reset: bool = False, max_ticks: int = 0,
-                 lane_id_base: int = 0):
+                 lane_id_base: int = 0, impl: str = "jump"):
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -84,6 +84,10 @@ class BatchedABREnv:
         self._h = h
         if lane_id_base:
             _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
+        if impl not in ("jump", "tick"):
+            raise ValueError("impl must be 'jump' (event-driven kernels) or 'tick'")
+        self.impl = impl
+        _lib.check(self.lib.abr_env_set_impl(self._h, 1 if impl == "tick" else 0))
         self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(self.n_lanes, dtype=torch.float32, device=self.device)
         self.done = torch.zeros(self.n_lanes, dtype=torch.uint8, device=self.device)

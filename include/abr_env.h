@@ -124,6 +124,11 @@ int abr_env_destroy(abr_env *env);
  * reproduces the unsharded one.  Default 0. */
 int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
 
+/* Which kernels serve reset/step: 0 (default) = event-driven, exact closed-form
+ * stepping of the float64 tick sequences; 1 = one loop trip per 0.01 s tick.  Both
+ * produce identical state; 1 exists as an independent cross-check. */
+int abr_env_set_impl(abr_env *env, int32_t impl);
+
 /*
  * run() state init (Simulator.py:95-133) plus the idle ticks up to the first
  * get_next_bitrate call site.  Lane i uses trace trace_id_dev[i]; its

@@ -35,13 +35,17 @@ def _cmp_step(f64, g, s, name):
     assert np.array_equal((fl >> 2) & 1, g["buffer_full"][:, s])
 
 
+IMPLS = ["jump", "tick"]   # event-driven kernels (default) and the tick-by-tick cross-check
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("name", ENV_GOLDENS)
-def test_step_matches_reference_goldens(name):
+def test_step_matches_reference_goldens(name, impl):
     """Replays the golden actions step by step; compares the full float64
     observation at EVERY call site with what the reference's run() frame held."""
     m, g = load_golden(name)
     N, V = g["actions"].shape
-    env = make_env(m, g["traces"], N)
+    env = make_env(m, g["traces"], N, impl=impl)
     obs = env.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
     acts = torch.from_numpy(g["actions"]).cuda()
     rew_sum = np.zeros(N)
@@ -96,7 +100,8 @@ def _random_case(seed, N, V=12, L=4.0, interval=1.0, n_traces=7, ragged=False, m
     dict(seed=1, N=1000), dict(seed=2, N=777, ragged=True), dict(seed=3, N=512, L=1.0, start_up=2.0),
     dict(seed=4, N=300, interval=0.3, bw=(0.1, 1.5)), dict(seed=5, N=256, max_buffer=5.0, start_up=4.0),
     dict(seed=6, N=1, V=3), dict(seed=7, N=65, L=2.5, interval=0.7, V=9)])
-def test_step_matches_oracle_seeded(oracle, case):
+@pytest.mark.parametrize("impl", IMPLS)
+def test_step_matches_oracle_seeded(oracle, case, impl):
     """Same seeded inputs through the HIP path and the C oracle (wrap-around of
     short ragged traces included, where the reference itself would raise)."""
     meta, traces, trace_id, offset, actions = _random_case(**case)
@@ -104,7 +109,7 @@ def test_step_matches_oracle_seeded(oracle, case):
                          meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions)
     N, V = actions.shape
-    env = make_env(meta, traces, N)
+    env = make_env(meta, traces, N, impl=impl)
     env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
     acts = torch.from_numpy(actions).cuda()
     for s in range(V):
@@ -140,8 +145,8 @@ def test_step_random_fused_equals_stepwise_and_oracle(oracle):
         assert np.array_equal(obs[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32))
     assert (out["done"].cpu().numpy()[:-1] == 0).all() and (out["done"].cpu().numpy()[-1] == 1).all()
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
-    # step-by-step twin
-    env2 = make_env(meta, traces, N)
+    # step-by-step twin, on the OTHER implementation
+    env2 = make_env(meta, traces, N, impl="tick")
     env2.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
     for s in range(V):
         o, r, d = env2.step(out["actions"][s].contiguous())

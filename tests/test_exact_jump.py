@@ -1,0 +1,110 @@
+"""Fuzzes csrc/abr_exact_jump.h (the closed-form 'add a float64 constant n times')
+on the CPU against the naive one-addition-per-tick loop: results must be
+bit-identical, including round-to-even ties, binade crossings, thresholds that
+sit exactly on reachable values, and the simulator's own constants."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "tests", "native", "exact_jump_harness.cpp")
+SO = os.path.join(ROOT, "tests", "native", "libexact_jump_harness.so")
+
+
+@pytest.fixture(scope="module")
+def H():
+    inc = os.path.join(ROOT, "abrsimulator_amd", "csrc")
+    if (not os.path.exists(SO) or os.path.getmtime(SO) < max(
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(inc, "abr_exact_jump.h")))):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-fno-fast-math", "-I", inc, SRC, "-o", SO])
+    lib = C.CDLL(SO)
+    for f in (lib.fuzz_ge, lib.fuzz_le, lib.fuzz_lt):
+        f.restype = C.c_int64
+    return lib
+
+
+def _run(fn, x0, c, thr, n):
+    x0 = np.ascontiguousarray(x0, np.float64); c = np.ascontiguousarray(c, np.float64)
+    thr = np.ascontiguousarray(thr, np.float64); n = np.ascontiguousarray(n, np.int32)
+    N = len(x0)
+    xo = np.zeros(N); ao = np.zeros(N, np.int32); ho = np.zeros(N, np.uint8)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    bad = fn(P(x0, C.c_double), P(c, C.c_double), P(thr, C.c_double), P(n, C.c_int32), C.c_int64(N),
+             P(xo, C.c_double), P(ao, C.c_int32), P(ho, C.c_uint8))
+    assert bad == -1, f"mismatch at case {bad}: x0={x0[bad]!r} c={c[bad]!r} thr={thr[bad]!r} n={n[bad]}"
+    return xo, ao, ho
+
+
+def test_download_accumulation_shapes(H):
+    """downloaded_size += bandwidth*dt until >= bitrate*L (Simulator.py:160-163)."""
+    rng = np.random.default_rng(1)
+    N = 400_000
+    bw = rng.uniform(0.05, 12.0, N).astype(np.float32).astype(np.float64)
+    c = bw * 0.01
+    x0 = np.where(rng.random(N) < 0.4, 0.0, rng.uniform(0, 20, N))
+    thr = rng.choice([0.3, 0.75, 1.2, 1.85, 2.85, 4.3, 1.0, 2.5, 5.0, 8.0], N) * rng.choice([1.0, 2.0, 3.0, 4.0], N)
+    n = rng.integers(1, 3000, N)
+    x, a, h = _run(H.fuzz_ge, x0, c, thr, n)
+    assert h.mean() > 0.2 and (a > 50).mean() > 0.3      # the jumps really ran
+
+
+def test_buffer_drain_shapes(H):
+    """buffer_level -= speed*dt until <= 0 (Simulator.py:184,194) or < max_buffer (:190)."""
+    rng = np.random.default_rng(2)
+    N = 400_000
+    x0 = np.where(rng.random(N) < 0.5, rng.integers(1, 7, N) * 4.0, rng.uniform(0.001, 30, N))
+    sd = rng.choice([0.01, 0.0125, 0.005, 0.02, 1.25 * 0.01, 0.75 * 0.01], N)
+    n = rng.integers(1, 4000, N)
+    _run(H.fuzz_le, x0, -sd, np.zeros(N), n)
+    thr = rng.choice([20.0, 3.0, 5.0, 9.0, 6.0], N)
+    x0b = thr + rng.uniform(0, 5, N)
+    _run(H.fuzz_lt, x0b, -sd, thr, n)
+    _run(H.fuzz_le, x0b, -sd, thr, n)
+
+
+def test_ties_and_exact_thresholds(H):
+    """Constants whose low bit is exactly half an ulp of the running value (round
+    to even), and thresholds placed exactly on / one ulp around reachable values."""
+    rng = np.random.default_rng(3)
+    N = 200_000
+    e = rng.integers(-8, 6, N)
+    base = np.ldexp(1.0, e)
+    # x0 = base * (1 + k*2^-52): odd and even mantissas; c = q*u + u/2 (a tie in binade e)
+    kmant = rng.integers(0, 1 << 20, N)
+    x0 = base * (1.0 + kmant * 2.0 ** -52)
+    u = base * 2.0 ** -52
+    q = rng.integers(1, 1 << 44, N).astype(np.float64)
+    c = q * u + u / 2
+    n = rng.integers(1, 500, N)
+    thr = x0 + c * rng.integers(1, 600, N)              # near a reachable value
+    _run(H.fuzz_ge, x0, c, thr, n)
+    _run(H.fuzz_ge, x0, c, np.nextafter(thr, np.inf), n)
+    _run(H.fuzz_ge, x0, c, np.nextafter(thr, -np.inf), n)
+    # decreasing, ties, thresholds on reachable values
+    x1 = base * (2.0 - kmant * 2.0 ** -52)
+    thr2 = np.maximum(x1 - c * rng.integers(1, 600, N), 0.0)
+    for t in (thr2, np.nextafter(thr2, np.inf), np.nextafter(thr2, -np.inf)):
+        _run(H.fuzz_le, x1, -c, t, n)
+        _run(H.fuzz_lt, x1, -c, t, n)
+
+
+def test_wild_ranges(H):
+    rng = np.random.default_rng(4)
+    N = 300_000
+    x0 = np.ldexp(rng.uniform(1, 2, N), rng.integers(-40, 40, N)) * (rng.random(N) > 0.1)
+    c = np.ldexp(rng.uniform(1, 2, N), rng.integers(-45, 30, N))
+    n = rng.integers(1, 2000, N)
+    thr = x0 + c * rng.uniform(0, 3000, N)
+    _run(H.fuzz_ge, x0, c, thr, n)
+    thr = np.maximum(x0 - c * rng.uniform(0, 3000, N), -1.0)
+    _run(H.fuzz_le, x0, -c, thr, n)
+    _run(H.fuzz_lt, x0, -c, thr, n)
+    # tiny and subnormal neighbourhoods
+    x0 = rng.uniform(0, 1e-300, N); c = rng.uniform(1e-310, 1e-302, N)
+    _run(H.fuzz_ge, x0, c, rng.uniform(0, 1e-299, N), n)
+    _run(H.fuzz_le, x0, -c, np.zeros(N), n)
