@@ -87,7 +87,8 @@ def build(force=False):
     """Compile csrc/abr_env.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(CSRC, "abr_env.hip")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "abr_env.h")
-    deps = [src, hdr, os.path.join(CSRC, "abr_exact_jump.h")]
+    deps = [src, hdr] + [os.path.join(CSRC, h) for h in
+                         ("abr_exact_jump.h", "abr_lane_jump.h", "abr_tick_tables.h")]
     stale = (not os.path.exists(SO_PATH)
              or os.path.getmtime(SO_PATH) < max(os.path.getmtime(d) for d in deps))
     if force or stale:

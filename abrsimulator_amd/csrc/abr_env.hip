@@ -26,7 +26,8 @@
 #include <vector>
 
 #include "abr_env.h"
-#include "abr_exact_jump.h"
+#include "abr_lane_jump.h"
+#include "abr_tick_tables.h"
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -452,91 +453,16 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// K1/K2, event-driven form: the same tick semantics without visiting every tick
+// K1/K2, event-driven form (default): abr_lane_jump.h does the per-lane work
 // ---------------------------------------------------------------------------
-// A step (call site -> next call site) is a handful of runs in which one
-// float64 variable receives the same constant every tick:
-//   phase A  downloaded_size += bandwidth*dt, one run per trace interval, until it
-//            reaches target_size at tick k_hit (abrx::chain<STOP_GE>);
-//            meanwhile buffer_level -= speed*dt while playing, until 0 (STOP_LE);
-//   hit tick buffer_level = (buffer_level + L) - speed*dt, flags, start-up exit;
-//   phase B  wait for availability: buffer_level drains for avail_tick - k ticks,
-//            then until buffer_level < max_buffer if buffer_full gates the download
-//            (STOP_LT).
-// abrx::chain executes each run in O(binades crossed) while producing the
-// bit-identical float64 value of the tick-by-tick loop (abr_exact_jump.h), and the
-// integer counters (ticks in start-up / rebuffering / playing, the latency
-// integral sum of k over playing ticks) have exact closed forms over a run.
-// State between the pieces is always "post-head": T1-T3 of tick s.k are done.
-struct LaneJ {
-    double buf;
-    long long sumk;
-    int32_t k, chunk_id, n_su, n_rb, n_play, j, tpos, tlen, avail_k, last_action;
-    bool su, be, bf;
-    const double *trace;
-};
+using abrx::LaneJ;
 
-// m full iterations (T4-T9 of a tick without a completion, then T1-T3 of the next)
-__device__ inline void lanej_idle(LaneJ &s, const EnvParams &p, int32_t m) {
-    if (m <= 0) return;
-    if (s.su) {
-        s.n_su += m;                                   // :137-138, buffer untouched
-    } else if (s.be) {
-        s.n_rb += m;                                   // :139-140, buffer stays 0
-    } else {
-        int32_t a = 0;
-        double b = s.buf;
-        const bool zero = abrx::chain<abrx::STOP_LE>(b, -p.sd, 0.0, m, a);     // :184,:194
-        s.n_play += a;
-        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
-        if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
-        s.buf = b;
-        s.bf = b >= p.max_buffer;                      // :190, as of the last tick executed
-    }
-    s.k += m;
-}
-
-// From a post-head state that is not downloading: advance to the next call site
-// (returns true) or to max_ticks (returns false).
-__device__ inline bool lanej_wait_call(LaneJ &s, const EnvParams &p) {
-    const int32_t mt = p.max_ticks;
-    if (s.k >= s.avail_k && !s.bf) return true;
-    int32_t w = s.avail_k - s.k;
-    if (w < 0) w = 0;
-    if (w > mt - s.k) w = mt - s.k;
-    lanej_idle(s, p, w);
-    if (s.k >= mt) return false;
-    if (s.bf) {
-        // buffer_full gates the next download (:144): drain until buffer_level < max_buffer
-        if (s.su || s.be) {
-            // nothing drains the buffer: the reference spins forever; run out the clock
-            if (s.su) s.n_su += mt - s.k; else s.n_rb += mt - s.k;
-            s.k = mt;
-            return false;
-        }
-        int32_t a = 0;
-        double b = s.buf;
-        const bool cleared = abrx::chain<abrx::STOP_LT>(b, -p.sd, p.max_buffer, mt - s.k, a);
-        s.n_play += a;
-        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
-        s.k += a;
-        s.be = b <= 0.0;
-        if (s.be) { b = 0.0; s.n_rb += 1; }
-        s.buf = b;
-        s.bf = !cleared;
-        if (!cleared) return false;
-    }
-    return s.k < mt || (s.k >= s.avail_k && !s.bf);
-}
-
-__device__ inline void lanej_init(LaneJ &s, const EnvParams &p, int32_t offset0) {
-    // Simulator.py:95-130, then T1-T3 of tick 0
-    s.buf = 0.0; s.sumk = 0;
-    s.k = 0; s.chunk_id = 0; s.n_su = 1; s.n_rb = 0; s.n_play = 0;
-    s.last_action = -1;
-    s.su = true; s.be = true; s.bf = false;
-    s.j = 0; s.tpos = offset0 % s.tlen;
-    s.avail_k = p.avail_tick[0];
+__device__ inline abrx::Tables make_tables(const EnvParams &p) {
+    abrx::Tables t;
+    t.G = p.G; t.interval_tick = p.interval_tick; t.avail_tick = p.avail_tick;
+    t.L = p.chunk_length; t.sd = p.sd; t.max_buffer = p.max_buffer;
+    t.start_up_length = p.start_up_length; t.V = p.video_length; t.max_ticks = p.max_ticks;
+    return t;
 }
 
 __device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
@@ -581,8 +507,8 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < p.n_lanes;
     const int32_t n_total = (MODE == 2) ? n_steps : 1;
-    const int32_t V = p.video_length, mt = p.max_ticks;
-    const double L = p.chunk_length;
+    const int32_t V = p.video_length;
+    const abrx::Tables tb = make_tables(p);
     LaneJ s;
     bool active = in_range, touched = in_range;
     uint8_t done = 0;
@@ -597,8 +523,8 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                 offset0 = offset_in ? offset_in[i] : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
-                lanej_init(s, p, offset0);
-                if (!lanej_wait_call(s, p)) done |= ABR_DONE_TIMEOUT;
+                abrx::lanej_init(s, tb, offset0);
+                if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                 write_obs_j(s, p, i, obs_out, 0.0);
             }
         } else {
@@ -632,89 +558,43 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                     write_obs_j(s, p, i, obs, last_bw);
                     active = false;
                 } else {
-                    const double target = p.ladder[a] * L;                   // :156
-                    // ---- phase A: downloaded_size over the trace intervals ----
-                    // catch j/tpos up with k (phase B moved k only)
-                    int32_t ke = p.interval_tick[s.j + 1];
-                    while (s.k >= ke) {
-                        s.j++;
-                        s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-                        ke = p.interval_tick[s.j + 1];
-                    }
-                    double bw = s.trace[s.tpos];
-                    const int32_t lim = mt - s.k;
-                    double dl = 0.0;
-                    int32_t n_dl = 0, kk = s.k;
-                    bool hit = false;
-                    while (!hit && n_dl < lim) {
-                        // prefetch the next interval while this one is integrated
-                        const int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-                        const double bw_next = s.trace[tn];
-                        const int32_t ke_next = p.interval_tick[s.j + 2];
-                        int32_t n = ke - kk;
-                        if (n > lim - n_dl) n = lim - n_dl;
-                        int32_t adds = 0;
-                        hit = abrx::chain<abrx::STOP_GE>(dl, bw * kDt, target, n, adds);   // :160-163
-                        n_dl += adds; kk += adds;
-                        if (!hit && kk >= ke) { s.j++; s.tpos = tn; bw = bw_next; ke = ke_next; }
-                    }
-                    // ---- buffer side of the ticks before the completing one ----
-                    lanej_idle(s, p, hit ? n_dl - 1 : n_dl);
-                    bool ended = false, timeout = !hit;
+                    const int32_t prev_action = s.last_action;
+                    const int32_t chunk = s.chunk_id;
+                    const abrx::StepResult r =
+                        abrx::lanej_step(s, tb, p.ladder[a] * p.chunk_length /* :156 */, a);
                     double var = 0.0;
-                    if (hit) {
-                        // ---- the completing tick (:163-170, then :174-202) ----
-                        const bool playing = !(s.be || s.su);
-                        double b = s.buf + L;                                  // :170
-                        if (playing) { s.sumk += s.k; s.n_play++; b = b - p.sd; }   // :184
-                        s.bf = b >= p.max_buffer;
-                        s.be = b <= 0.0;
-                        if (s.be) b = 0.0;
-                        s.buf = b;
-                        s.su = s.su && !(b >= p.start_up_length);              // :201-202
-                        s.k++;
-                        const double bwm = dl / p.G[n_dl];                     // :164
-                        const int64_t h = (int64_t)s.chunk_id * p.n_lanes + i;
-                        p.bw_hist[h] = bwm;
+                    if (r.hit) {
+                        const int64_t h = (int64_t)chunk * p.n_lanes + i;
+                        p.bw_hist[h] = r.bw;                                   // :164
                         p.action_hist[h] = (uint8_t)a;                         // :165
-                        last_bw = bwm;
-                        hist_s = hist_s + 1.0 / bwm;    // sum(1/x), list order (mpc.py:86-88)
+                        last_bw = r.bw;
+                        hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
                         hist_n = hist_n + 1.0;
-                        if (s.last_action >= 0) var = fabs(p.ladder[a] - p.ladder[s.last_action]);
-                        s.last_action = a;
-                        s.chunk_id++;                                          // :166
-                        s.avail_k = p.avail_tick[s.chunk_id];
-                        ended = s.chunk_id >= V;                               // :207-208
-                        timeout = !ended && s.k >= mt;
-                        if (!ended && !timeout) {
-                            s.n_su += s.su ? 1 : 0;                            // T1 of the next tick
-                            s.n_rb += (!s.su && s.be) ? 1 : 0;
-                            timeout = !lanej_wait_call(s, p);                  // phase B
-                        }
+                        if (prev_action >= 0) var = fabs(p.ladder[a] - p.ladder[prev_action]);
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
-                    const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
-                                     p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
-                    if (ended) done |= ABR_DONE_EPISODE;
-                    if (timeout) done |= ABR_DONE_TIMEOUT;
-                    if (reward_out) reward_out[o] = (float)r;
+                    const double rew = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
+                                       p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
+                    if (r.ended) done |= ABR_DONE_EPISODE;
+                    if (r.timeout) done |= ABR_DONE_TIMEOUT;
+                    if (reward_out) reward_out[o] = (float)rew;
                     if (done_out) done_out[o] = done;
                     n_su_obs = s.n_su; n_rb_obs = s.n_rb;
-                    if (ended || timeout) {
+                    if (r.ended || r.timeout) {
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
                         p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
-                        if (p.auto_reset && ended) {
+                        if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
                             for (int c = 0; c < V; c++)
                                 p.ep_actions[(int64_t)c * p.n_lanes + i] =
                                     p.action_hist[(int64_t)c * p.n_lanes + i];
-                            lanej_init(s, p, offset0);
+                            abrx::lanej_init(s, tb, offset0);
                             episode_no++;
                             n_su_obs = 0; n_rb_obs = 0;
                             last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
                             done = 0;
-                            if (!lanej_wait_call(s, p)) done |= ABR_DONE_TIMEOUT;
+                            if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                         }
                     }
                     write_obs_j(s, p, i, obs, last_bw);
@@ -867,44 +747,16 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     if (workspace_bytes < L.total)
         return fail(ABR_E_WORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, L.total);
 
-    // ---- universal tick tables, float64 on the host (SURVEY.md 7 "Hard parts" 1) ----
+    // ---- universal tick tables, float64 on the host (abr_tick_tables.h) ----
     const int32_t mt = L.max_ticks;
-    std::vector<double> G((size_t)mt + 2), GP((size_t)mt + 2);
-    const double sd = cfg->speed * kDt;      // play_speed * dt as the reference forms it (:182)
-    {
-        double g = 0.0, gp = 0.0;            // global_time = 0.0 (:128); play_time = 0 (:115)
-        for (int32_t n = 0; n < mt + 2; n++) {
-            G[n] = g; GP[n] = gp;
-            g += kDt;                        // :205 (and :138,:140,:161)
-            gp += sd;                        // :182-183
-        }
-    }
-    std::vector<int32_t> itick((size_t)L.n_intervals + 2, INT_MAX);
-    {
-        int64_t jcur = 0;
-        for (int32_t k = 0; k <= mt && jcur < L.n_intervals + 2; k++) {
-            int64_t idx = (int64_t)(G[k] / cfg->interval);      // :158
-            while (jcur <= idx && jcur < L.n_intervals + 2) itick[jcur++] = k;
-        }
-    }
-    // ticks per block of the tick loop: at most one interval boundary per block
-    int32_t t_block = 128;
-    for (size_t jj = 0; jj + 1 < itick.size() && itick[jj + 1] != INT_MAX; jj++) {
-        int32_t len = itick[jj + 1] - itick[jj];
-        if (len < t_block) t_block = len;
-    }
+    abrx::TickTables tt = abrx::build_tick_tables(cfg->interval, cfg->chunk_length, cfg->speed,
+                                                  cfg->video_length, mt, L.n_intervals);
+    std::vector<double> &G = tt.G, &GP = tt.GP;
+    std::vector<int32_t> &itick = tt.interval_tick, &atick = tt.avail_tick;
+    const double sd = tt.sd;
+    const int32_t P = tt.play_ticks_per_chunk;
+    int32_t t_block = tt.min_interval_ticks < 128 ? tt.min_interval_ticks : 128;
     if (t_block < 1) t_block = 1;
-    std::vector<int32_t> atick((size_t)cfg->video_length + 2, INT_MAX);
-    {
-        int64_t ccur = 0;
-        for (int32_t k = 0; k <= mt && ccur < cfg->video_length; k++) {
-            int64_t avail = (int64_t)(G[k] / cfg->chunk_length) - 1;   // :143
-            while (ccur <= avail && ccur < cfg->video_length) atick[ccur++] = k;
-        }
-    }
-    int32_t P = INT_MAX;
-    for (int32_t n = 1; n < mt + 2; n++)
-        if (GP[n] >= cfg->chunk_length) { P = n; break; }      // :185
     if (P == INT_MAX)
         return fail(ABR_E_UNSUPPORTED, "max_ticks %d too small to play one chunk", mt);
 

@@ -91,16 +91,22 @@ ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out)
         if (inb >= 2 && a < n && e > 0 && e < 2046) {
             // steady state: jump m additions that stay strictly inside the binade
             // and strictly before the stop
-            double lim;          // first value NOT allowed: results must stay on the near side of it
+            // `lim` bounds the jumped results: they must stay inside the binade and
+            // before the stop.  Going down, the binade bottom 2^e itself is excluded:
+            // a steady step that lands exactly on 2^e means the exact difference lies
+            // just below it, in the finer grid of the next binade, so that step has to
+            // be a real subtraction.
+            double lim;
+            bool strict = true;  // results must be strictly beyond lim (else: may equal it)
             double mf;
             if (STOP == STOP_GE) {
-                lim = pow2_biased(e + 1);           // exclusive top of the binade
-                if (thr < lim) lim = thr;           // and results must stay < thr
+                lim = pow2_biased(e + 1);           // results stay < 2^(e+1) ...
+                if (thr < lim) lim = thr;           // ... and < thr
                 mf = (lim - x) / d;
             } else {
-                lim = pow2_biased(e);               // inclusive bottom: results must stay >= 2^e
-                if (STOP == STOP_LE) { if (thr >= lim) lim = thr; }   // ... and > thr   (see below)
-                else                 { if (thr > lim) lim = thr; }    // ... and >= thr
+                lim = pow2_biased(e);               // results stay > 2^e ...
+                if (STOP == STOP_LE) { if (thr >= lim) lim = thr; }              // ... and > thr
+                else if (thr > lim) { lim = thr; strict = false; }               // ... and >= thr
                 mf = (x - lim) / (-d);
             }
             // clamp before converting (mf may be huge or, from rounding, slightly negative)
@@ -112,12 +118,10 @@ ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out)
             if (STOP == STOP_GE) {
                 while (m > 0 && !(x + (double)m * d < lim)) m--;
                 while (m < n - a && (x + (double)(m + 1) * d < lim)) m++;
-            } else if (STOP == STOP_LE && thr >= pow2_biased(e)) {
-                // lim == thr: results must stay > thr
+            } else if (strict) {
                 while (m > 0 && !(x + (double)m * d > lim)) m--;
                 while (m < n - a && (x + (double)(m + 1) * d > lim)) m++;
             } else {
-                // results must stay >= lim (binade bottom, or thr for STOP_LT)
                 while (m > 0 && !(x + (double)m * d >= lim)) m--;
                 while (m < n - a && (x + (double)(m + 1) * d >= lim)) m++;
             }

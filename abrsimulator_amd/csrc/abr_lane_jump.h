@@ -1,0 +1,182 @@
+// abr_lane_jump.h -- one lane of the event-driven environment step (host + device).
+//
+// The same tick semantics as the reference's Simulator.run() loop
+// (Simulator.py:135-208 under R1-R3) without visiting every tick.  A step (ABR
+// call site -> next call site) is a handful of runs in which one float64
+// variable receives the same constant every tick:
+//   phase A  downloaded_size += bandwidth*dt, one run per trace interval, until it
+//            reaches target_size at tick k_hit            (chain<STOP_GE>, :160-163)
+//            meanwhile buffer_level -= speed*dt while playing, until 0
+//                                                          (chain<STOP_LE>, :184,:194)
+//   hit tick buffer_level = (buffer_level + L) - speed*dt, flags, start-up exit
+//                                                          (:170,:184,:190-202)
+//   phase B  wait for the next chunk to become available (:143): buffer_level drains
+//            for avail_tick - k ticks, then until buffer_level < max_buffer when
+//            buffer_full gates the download               (chain<STOP_LT>, :144,:190)
+// abrx::chain executes each run in O(binades crossed) and returns the bit-identical
+// float64 value of the tick-by-tick loop (abr_exact_jump.h); the integer counters
+// (ticks in start-up / rebuffering / playing, and the latency integral: sum of k
+// over playing ticks) have exact closed forms over a run.
+//
+// State between the pieces is always "post-head": T1-T3 (:137-149) of tick s.k are
+// done.  A download cannot pause inside phase A: buffer_full only turns on in a tick
+// that completes a chunk (buffer_level grows nowhere else), availability is
+// monotone in time.
+//
+// Plain C++ so that tests/native can run it on the CPU against the oracle; the
+// product only ever runs it inside the HIP kernels of abr_env.hip.
+#ifndef ABR_LANE_JUMP_H
+#define ABR_LANE_JUMP_H
+
+#include "abr_exact_jump.h"
+
+namespace abrx {
+
+constexpr double kTickDt = 0.01;   // Simulator.py:133
+
+struct Tables {
+    const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
+    const int32_t *interval_tick;  // first tick k with int(G[k]/interval) >= j          (:158)
+    const int32_t *avail_tick;     // first tick k with int(G[k]/chunk_length) - 1 >= c  (:143)
+    double L, sd, max_buffer, start_up_length;
+    int32_t V, max_ticks;
+};
+
+struct LaneJ {
+    double buf;                    // buffer_level
+    long long sumk;                // sum of tick indices of playing ticks (latency integral)
+    int32_t k, chunk_id, n_su, n_rb, n_play, j, tpos, tlen, avail_k, last_action;
+    bool su, be, bf;               // start_up, buffer_empty, buffer_full
+    const double *trace;
+};
+
+ABR_HD void lanej_init(LaneJ &s, const Tables &t, int32_t offset0) {
+    // Simulator.py:95-130, then T1-T3 of tick 0 (start_up_time += dt)
+    s.buf = 0.0; s.sumk = 0;
+    s.k = 0; s.chunk_id = 0; s.n_su = 1; s.n_rb = 0; s.n_play = 0;
+    s.last_action = -1;
+    s.su = true; s.be = true; s.bf = false;
+    s.j = 0; s.tpos = offset0 % s.tlen;
+    s.avail_k = t.avail_tick[0];
+}
+
+// m full iterations: T4-T9 of a tick in which no chunk completes, then T1-T3 of the next
+ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
+    if (m <= 0) return;
+    if (s.su) {
+        s.n_su += m;                                   // :137-138; nothing plays, buffer untouched
+    } else if (s.be) {
+        s.n_rb += m;                                   // :139-140; buffer stays 0
+    } else {
+        int32_t a = 0;
+        double b = s.buf;
+        const bool zero = chain<STOP_LE>(b, -t.sd, 0.0, m, a);                 // :184,:194
+        s.n_play += a;
+        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
+        if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
+        s.buf = b;
+        s.bf = b >= t.max_buffer;                      // :190, as of the last tick executed
+    }
+    s.k += m;
+}
+
+// From a post-head state that is not downloading: advance to the next call site
+// (returns true) or to max_ticks (returns false).
+ABR_HD bool lanej_wait_call(LaneJ &s, const Tables &t) {
+    const int32_t mt = t.max_ticks;
+    if (s.k >= s.avail_k && !s.bf) return true;
+    int32_t w = s.avail_k - s.k;
+    if (w < 0) w = 0;
+    if (w > mt - s.k) w = mt - s.k;
+    lanej_idle(s, t, w);
+    if (s.k >= mt) return false;
+    if (s.bf) {
+        // buffer_full gates the next download (:144): drain until buffer_level < max_buffer
+        if (s.su || s.be) {
+            // nothing drains the buffer: the reference spins forever; run out the clock
+            if (s.su) s.n_su += mt - s.k; else s.n_rb += mt - s.k;
+            s.k = mt;
+            return false;
+        }
+        int32_t a = 0;
+        double b = s.buf;
+        const bool cleared = chain<STOP_LT>(b, -t.sd, t.max_buffer, mt - s.k, a);
+        s.n_play += a;
+        s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
+        s.k += a;
+        s.be = b <= 0.0;
+        if (s.be) { b = 0.0; s.n_rb += 1; }
+        s.buf = b;
+        s.bf = !cleared;
+        if (!cleared) return false;
+    }
+    return true;
+}
+
+struct StepResult {
+    double bw;        // downloaded_size / download_time of the chunk (:164), valid when hit
+    bool hit;         // the chunk completed
+    bool ended;       // chunk_id >= video_length (:207-208)
+    bool timeout;     // ran into max_ticks
+};
+
+// One decision: from a call site, download a chunk of target_size, then run to
+// the next call site.  `action` only labels the step (last_action).
+ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t action) {
+    StepResult r;
+    r.bw = 0.0; r.hit = false; r.ended = false; r.timeout = false;
+    const int32_t mt = t.max_ticks;
+    // ---- phase A: downloaded_size over the trace intervals ----
+    int32_t ke = t.interval_tick[s.j + 1];
+    while (s.k >= ke) {                       // phase B moved k only: catch j/tpos up
+        s.j++;
+        s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+        ke = t.interval_tick[s.j + 1];
+    }
+    double bw = s.trace[s.tpos];
+    const int32_t lim = mt - s.k;
+    double dl = 0.0;
+    int32_t n_dl = 0, kk = s.k;
+    bool hit = false;
+    while (!hit && n_dl < lim) {
+        // prefetch the next interval while this one is integrated
+        const int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+        const double bw_next = s.trace[tn];
+        const int32_t ke_next = t.interval_tick[s.j + 2];
+        int32_t n = ke - kk;
+        if (n > lim - n_dl) n = lim - n_dl;
+        int32_t adds = 0;
+        hit = chain<STOP_GE>(dl, bw * kTickDt, target, n, adds);             // :160-163
+        n_dl += adds; kk += adds;
+        if (!hit && kk >= ke) { s.j++; s.tpos = tn; bw = bw_next; ke = ke_next; }
+    }
+    // ---- buffer side of the ticks before the completing one ----
+    lanej_idle(s, t, hit ? n_dl - 1 : n_dl);
+    if (!hit) { r.timeout = true; return r; }
+    // ---- the completing tick (:163-170, then :174-202) ----
+    const bool playing = !(s.be || s.su);
+    double b = s.buf + t.L;                                                  // :170
+    if (playing) { s.sumk += s.k; s.n_play++; b = b - t.sd; }                // :184
+    s.bf = b >= t.max_buffer;                                                // :190
+    s.be = b <= 0.0;                                                         // :194
+    if (s.be) b = 0.0;
+    s.buf = b;
+    s.su = s.su && !(b >= t.start_up_length);                                // :201-202
+    s.k++;                                                                   // :205
+    r.hit = true;
+    r.bw = dl / t.G[n_dl];                                                   // :164
+    s.last_action = action;
+    s.chunk_id++;                                                            // :166
+    s.avail_k = t.avail_tick[s.chunk_id];
+    r.ended = s.chunk_id >= t.V;                                             // :207-208
+    r.timeout = !r.ended && s.k >= mt;
+    if (!r.ended && !r.timeout) {
+        s.n_su += s.su ? 1 : 0;                                              // T1 of the next tick
+        s.n_rb += (!s.su && s.be) ? 1 : 0;
+        r.timeout = !lanej_wait_call(s, t);                                  // phase B
+    }
+    return r;
+}
+
+}  // namespace abrx
+#endif

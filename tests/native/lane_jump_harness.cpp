@@ -1,0 +1,80 @@
+// CPU harness for abr_lane_jump.h + abr_tick_tables.h: replays episodes through the
+// event-driven lane step ON THE HOST so tests can compare it with the oracle on
+// millions of lane-steps without a GPU.  Built by tests/test_lane_jump_cpu.py.
+#include <stdint.h>
+#include <stdlib.h>
+#include "abr_lane_jump.h"
+#include "abr_tick_tables.h"
+
+struct Ctx {
+    abrx::TickTables tt;
+    abrx::Tables t;
+    double ladder[16];
+    int n_rates;
+};
+
+extern "C" {
+
+void *lj_create(double interval, double L, double speed, int32_t V, double max_buffer,
+                double start_up_length, int32_t max_ticks, const double *ladder, int32_t n_rates) {
+    Ctx *c = new Ctx;
+    int32_t n_iv = (int32_t)((double)max_ticks * 0.01 / interval + 4.0);
+    c->tt = abrx::build_tick_tables(interval, L, speed, V, max_ticks, n_iv);
+    c->t.G = c->tt.G.data();
+    c->t.interval_tick = c->tt.interval_tick.data();
+    c->t.avail_tick = c->tt.avail_tick.data();
+    c->t.L = L; c->t.sd = c->tt.sd; c->t.max_buffer = max_buffer; c->t.start_up_length = start_up_length;
+    c->t.V = V; c->t.max_ticks = max_ticks;
+    c->n_rates = n_rates;
+    for (int i = 0; i < n_rates; i++) c->ladder[i] = ladder[i];
+    return c;
+}
+void lj_destroy(void *h) { delete (Ctx *)h; }
+
+// One episode.  Per-step outputs are taken AT each call site (before action s is applied):
+// rec[s*8 + ..] = global_time, rebuffer_time, start_up_time, play_time, buffer_level,
+//                 last_bw, sumk (as double), flags(su|be<<1|bf<<2)
+// fin[0..5] = global_time, rebuffer_time, start_up_time, play_time, buffer_level, sumk; fin_i[0]=n_play
+// returns 0, or -2 on timeout
+int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const int32_t *actions,
+               double *rec, double *bw_out, double *fin, int32_t *fin_i) {
+    Ctx *c = (Ctx *)h;
+    const abrx::Tables &t = c->t;
+    abrx::LaneJ s;
+    s.trace = trace; s.tlen = tlen;
+    abrx::lanej_init(s, t, offset);
+    if (!abrx::lanej_wait_call(s, t)) return -2;
+    double last_bw = 0.0;
+    for (int step = 0; step < t.V; step++) {
+        double *r = rec + (size_t)step * 8;
+        r[0] = t.G[s.k]; r[1] = t.G[s.n_rb]; r[2] = t.G[s.n_su]; r[3] = c->tt.GP[s.n_play];
+        r[4] = s.buf; r[5] = last_bw; r[6] = (double)s.sumk;
+        r[7] = (double)((s.su ? 1 : 0) | (s.be ? 2 : 0) | (s.bf ? 4 : 0));
+        int a = actions[step];
+        abrx::StepResult sr = abrx::lanej_step(s, t, c->ladder[a] * t.L, a);
+        if (sr.timeout) return -2;
+        last_bw = sr.bw;
+        bw_out[step] = sr.bw;
+        if (sr.ended != (step == t.V - 1)) return -5;
+    }
+    fin[0] = t.G[s.k]; fin[1] = t.G[s.n_rb]; fin[2] = t.G[s.n_su]; fin[3] = c->tt.GP[s.n_play];
+    fin[4] = s.buf; fin[5] = (double)s.sumk;
+    fin_i[0] = s.n_play;
+    return 0;
+}
+
+int64_t lj_batch(void *h, const double *traces, const int64_t *trace_off, const int32_t *trace_len,
+                 const int32_t *trace_id, const int32_t *offset, const int32_t *actions,
+                 int32_t n_lanes, double *rec, double *bw_out, double *fin, int32_t *fin_i) {
+    Ctx *c = (Ctx *)h;
+    const int V = c->t.V;
+    for (int32_t i = 0; i < n_lanes; i++) {
+        int tid = trace_id[i];
+        int rc = lj_episode(h, traces + trace_off[tid], trace_len[tid], offset[i],
+                            actions + (size_t)i * V, rec + (size_t)i * V * 8,
+                            bw_out + (size_t)i * V, fin + (size_t)i * 6, fin_i + i);
+        if (rc) return -(1000 + (int64_t)i * 10 - rc);
+    }
+    return 0;
+}
+}

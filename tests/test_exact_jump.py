@@ -108,3 +108,35 @@ def test_wild_ranges(H):
     x0 = rng.uniform(0, 1e-300, N); c = rng.uniform(1e-310, 1e-302, N)
     _run(H.fuzz_ge, x0, c, rng.uniform(0, 1e-299, N), n)
     _run(H.fuzz_le, x0, -c, np.zeros(N), n)
+
+
+def test_landing_exactly_on_a_power_of_two(H):
+    """A steady downward step that lands exactly on 2^e is NOT an in-binade step: the
+    exact difference lies just below 2^e, on the finer grid of the next binade
+    (found by the env goldens: 2.0299999999999994 - 3 * 0.01)."""
+    rng = np.random.default_rng(5)
+    xs, cs, ns = [], [], []
+    for e in range(-6, 7):
+        y = 2.0 ** e
+        for c in list(rng.uniform(0.001, 0.2, 40) * y) + [0.01, 0.0125, 0.005]:
+            if not (c < y / 8):
+                continue
+            x = y * 1.5
+            x1 = x - c; x2 = x1 - c
+            d = x1 - x2                       # the steady in-binade decrement
+            for j in (1, 2, 3, 7, 20):
+                x0 = y + j * d
+                if x0 < 2 * y:
+                    xs.append(x0); cs.append(c); ns.append(j + 50)
+    xs = np.array(xs); cs = np.array(cs); ns = np.array(ns, np.int32)
+    _run(H.fuzz_le, xs, -cs, np.zeros(len(xs)), ns)
+    _run(H.fuzz_lt, xs, -cs, xs / 3, ns)
+    assert _run(H.fuzz_le, [2.0299999999999994], [-0.01], [0.0], [72])[0][0] == 1.3099999999999992
+    # the upward twin: landing exactly on 2^(e+1) from below
+    _run(H.fuzz_ge, 2 * np.array(xs) - (xs - 0) , cs, np.full(len(xs), 1e9), ns)
+    xs2 = []
+    for x0, c in zip(xs, cs):
+        y = 2.0 ** np.ceil(np.log2(x0))
+        x = y * 0.75; x1 = x + c; x2 = x1 + c; d = x2 - x1
+        xs2.append(y - 3 * d)
+    _run(H.fuzz_ge, np.array(xs2), cs, np.full(len(xs), 1e9), ns)

@@ -1,0 +1,122 @@
+"""The event-driven lane step (csrc/abr_lane_jump.h), compiled for the HOST, against
+the reference-generated goldens and against the C oracle on large seeded sets.
+This is the same source the HIP kernels compile for gfx950; running it on the CPU
+lets the exactness claim be fuzzed over millions of lane-steps without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ENV_GOLDENS, ROOT, load_golden
+
+SRC = os.path.join(ROOT, "tests", "native", "lane_jump_harness.cpp")
+SO = os.path.join(ROOT, "tests", "native", "liblane_jump_harness.so")
+INC = os.path.join(ROOT, "abrsimulator_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def H():
+    deps = [SRC] + [os.path.join(INC, f) for f in ("abr_lane_jump.h", "abr_exact_jump.h", "abr_tick_tables.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-fno-fast-math", "-I", INC, SRC, "-o", SO])
+    lib = C.CDLL(SO)
+    lib.lj_create.restype = C.c_void_p
+    lib.lj_batch.restype = C.c_int64
+    return lib
+
+
+def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0):
+    from oracle.oracle import pack_traces
+    ladder = np.asarray(meta["ladder"], np.float64)
+    V = meta["video_length"]
+    if not max_ticks:
+        max_ticks = int(32 * V * np.ceil(meta["chunk_length"] / 0.01))
+    h = H.lj_create(C.c_double(meta["interval"]), C.c_double(meta["chunk_length"]),
+                    C.c_double(meta.get("speed", 1.0)), C.c_int32(V), C.c_double(meta["max_buffer"]),
+                    C.c_double(meta["start_up_length"]), C.c_int32(max_ticks),
+                    ladder.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(len(ladder)))
+    flat, off, lens = pack_traces(traces)
+    trace_id = np.ascontiguousarray(trace_id, np.int32); offset = np.ascontiguousarray(offset, np.int32)
+    actions = np.ascontiguousarray(actions, np.int32)
+    N = actions.shape[0]
+    rec = np.zeros((N, V, 8)); bw = np.zeros((N, V)); fin = np.zeros((N, 6)); fin_i = np.zeros(N, np.int32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = H.lj_batch(C.c_void_p(h), P(flat, C.c_double), P(off, C.c_int64), P(lens, C.c_int32),
+                    P(trace_id, C.c_int32), P(offset, C.c_int32), P(actions, C.c_int32), C.c_int32(N),
+                    P(rec, C.c_double), P(bw, C.c_double), P(fin, C.c_double), P(fin_i, C.c_int32))
+    H.lj_destroy(C.c_void_p(h))
+    assert rc == 0, rc
+    return rec, bw, fin, fin_i
+
+
+def _check(rec, bw, fin, steps, bwo, fino, sd=0.01):
+    names = ["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level", "last_bandwidth"]
+    for c, k in enumerate(names):
+        bad = np.argwhere(rec[:, :, c] != steps[k])
+        assert bad.size == 0, (k, bad[:3], rec[tuple(bad[0])][c], steps[k][tuple(bad[0])])
+    fl = rec[:, :, 7].astype(np.int32)
+    assert np.array_equal(fl & 1, steps["start_up"]) and np.array_equal((fl >> 1) & 1, steps["buffer_empty"])
+    assert np.array_equal((fl >> 2) & 1, steps["buffer_full"])
+    assert np.array_equal(bw, bwo)
+    for c, k in enumerate(["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]):
+        assert np.array_equal(fin[:, c], fino[k]), k
+
+
+@pytest.mark.parametrize("name", ENV_GOLDENS)
+def test_goldens_bit_exact(H, name):
+    m, g = load_golden(name)
+    rec, bw, fin, fin_i = run_jump(H, m, list(g["traces"]), g["trace_id"], g["offset"], g["actions"])
+    steps = {k: g[k] for k in ["global_time", "rebuffer_time", "start_up_time", "play_time",
+                               "buffer_level", "start_up", "buffer_empty", "buffer_full"]}
+    steps["last_bandwidth"] = g["arg_last_bandwidth"]
+    fino = {k: g["final_" + k] for k in ["global_time", "rebuffer_time", "start_up_time", "play_time",
+                                         "buffer_level"]}
+    _check(rec, bw, fin, steps, g["final_bandwidths"], fino)
+    # the integer latency integral reproduces average_latency to ~1e-12
+    sd = m.get("speed", 1.0) * 0.01
+    n_play = fin_i.astype(np.float64)
+    lat = (0.01 * fin[:, 5] - sd * (n_play * (n_play - 1) / 2)) / fin[:, 3]
+    assert np.allclose(lat, g["final_average_latency"], rtol=1e-9)
+
+
+CASES = [
+    dict(seed=1, N=4000, V=24), dict(seed=2, N=3000, V=16, ragged=True),
+    dict(seed=3, N=3000, V=40, L=1.0, start_up=2.0, ladder=(1, 2.5, 5, 8), bw=(0.5, 10.0)),
+    dict(seed=4, N=1500, V=12, interval=0.3, bw=(0.1, 1.5)),
+    dict(seed=5, N=2000, V=20, max_buffer=5.0, start_up=4.0, bw=(2.0, 12.0)),
+    dict(seed=6, N=2000, V=20, L=2.0, max_buffer=3.0, start_up=4.0, interval=0.5, bw=(2.0, 12.0)),
+    dict(seed=7, N=1500, V=12, L=2.5, interval=0.7),
+    dict(seed=8, N=1500, V=12, speed=1.25), dict(seed=9, N=1500, V=12, speed=0.8, bw=(1.0, 8.0)),
+    dict(seed=10, N=1500, V=16, round_bw=True),          # integer-ish bandwidths: knife edges
+    dict(seed=11, N=1500, V=16, L=3.0, interval=0.05, start_up=3.0, max_buffer=9.0),
+]
+
+
+def _case(seed, N, V=12, L=4.0, interval=1.0, n_traces=16, ragged=False, max_buffer=20.0,
+          start_up=8.0, bw=(0.2, 6.0), ladder=(0.3, 0.75, 1.2, 1.85, 2.85, 4.3), speed=1.0,
+          round_bw=False):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(300, 3001, n_traces) if ragged else np.full(n_traces, 4000)
+    if round_bw:
+        traces = [rng.choice([0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 4.8, 6.0], l) for l in lens]
+    else:
+        traces = [rng.uniform(bw[0], bw[1], l).astype(np.float32).astype(np.float64) for l in lens]
+    meta = dict(ladder=list(ladder), chunk_length=L, video_length=V, max_buffer=max_buffer,
+                start_up_length=start_up, interval=interval, weights=[4.3, 1, 1, 0.1], speed=speed)
+    trace_id = rng.integers(0, n_traces, N).astype(np.int32)
+    offset = np.array([rng.integers(0, lens[t]) for t in trace_id], np.int32)
+    actions = rng.integers(0, len(ladder), (N, V)).astype(np.int32)
+    return meta, traces, trace_id, offset, actions
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_seeded_against_oracle(H, oracle, case):
+    meta, traces, trace_id, offset, actions = _case(**case)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
+    steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions)
+    rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions)
+    _check(rec, bw, fin, steps, bwo, fino)
