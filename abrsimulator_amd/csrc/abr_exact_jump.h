@@ -68,6 +68,96 @@ ABR_HD bool stop_hit(double x, double thr) {
     return STOP == STOP_GE ? (x >= thr) : (STOP == STOP_LE ? (x <= thr) : (x < thr));
 }
 
+// Reciprocal estimate for the jump-length guess (the guess is corrected exactly).
+ABR_HD double rcp_est(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(d);      // v_rcp_f64
+#else
+    return 1.0 / d;
+#endif
+}
+
+// Running state of one chain, so that a caller can interleave other work (the
+// download integration advances through trace intervals between segments).
+struct ChainState {
+    double x;      // current value
+    double d;      // last in-binade increment (valid when inb >= 1)
+    int32_t inb;   // consecutive additions that stayed in one binade
+};
+
+// One SEGMENT of a chain: up to three real additions (the one that may cross a
+// binade plus the two that establish the steady increment) followed by one exact
+// jump to the end of the binade / just before the stop / the end of the budget.
+// Performs at most n additions; returns how many (>= 1 when n >= 1) and sets
+// `hit` when the last addition satisfied the STOP predicate.
+// Straight-line and predicated on purpose: this is the body of the GPU hot loop.
+template <int STOP>
+ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit) {
+    double x = cs.x, d = cs.d;
+    int32_t inb = cs.inb, a = 0;
+    hit = false;
+    // ---- up to three real additions ----
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 3; s++) {
+        const bool go = (a < n) && !hit && (s == 0 || inb < 2);
+        const double xn = x + c;
+        const double dn = xn - x;        // exact whenever xn and x share a binade
+        const bool same = expo(xn) == expo(x);
+        if (go) {
+            inb = same ? inb + 1 : 0;
+            d = dn;
+            x = xn;
+            a++;
+            hit = stop_hit<STOP>(x, thr);
+        }
+    }
+    // ---- one exact jump in the steady state ----
+    const int e = expo(x);
+    if (!hit && inb >= 2 && a < n && e > 0 && e < 2046) {
+        // `lim` bounds the jumped results: they must stay inside the binade and before
+        // the stop.  Going down, the binade bottom 2^e itself is excluded: a steady step
+        // that lands exactly on 2^e means the exact difference lies just below it, on the
+        // finer grid of the next binade, so that step has to be a real subtraction.
+        double lim, gap;
+        bool strict = true;              // results strictly beyond lim (else: may equal it)
+        if (STOP == STOP_GE) {
+            lim = pow2_biased(e + 1);               // results stay < 2^(e+1) ...
+            if (thr < lim) lim = thr;               // ... and < thr
+            gap = lim - x;
+        } else {
+            lim = pow2_biased(e);                   // results stay > 2^e ...
+            if (STOP == STOP_LE) { if (thr >= lim) lim = thr; }                  // ... and > thr
+            else if (thr > lim) { lim = thr; strict = false; }                   // ... and >= thr
+            gap = x - lim;
+        }
+        const double ad = (STOP == STOP_GE) ? d : -d;
+        double mf = gap * rcp_est(ad);
+        const double cap = (double)(n - a);
+        if (!(mf > 0.0)) mf = 0.0;
+        if (mf > cap) mf = cap;
+        int32_t m = (int32_t)mf;
+        // exact corrections (x + m*d is exact while it stays inside the binade); the
+        // estimate is off by at most one except for astronomically long jumps
+        const int32_t room = n - a;
+        if (STOP == STOP_GE) {
+            while (m > 0 && !(x + (double)m * d < lim)) m--;
+            while (m < room && (x + (double)(m + 1) * d < lim)) m++;
+        } else if (strict) {
+            while (m > 0 && !(x + (double)m * d > lim)) m--;
+            while (m < room && (x + (double)(m + 1) * d > lim)) m++;
+        } else {
+            while (m > 0 && !(x + (double)m * d >= lim)) m--;
+            while (m < room && (x + (double)(m + 1) * d >= lim)) m++;
+        }
+        x = x + (double)m * d;
+        a += m;
+    }
+    cs.x = x; cs.d = d; cs.inb = inb;
+    return a;
+}
+
 // Performs up to n additions x <- fl(x + c) and stops right after the first whose
 // result satisfies the STOP predicate against thr.  Returns true if it stopped on
 // the predicate; a_out = number of additions performed (1-based index of the
@@ -76,60 +166,12 @@ ABR_HD bool stop_hit(double x, double thr) {
 // tests/test_exact_jump.py).
 template <int STOP>
 ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out) {
-    double x = x_io;
+    ChainState cs;
+    cs.x = x_io; cs.d = 0.0; cs.inb = 0;
     int32_t a = 0;
-    int inb = 0;                 // consecutive additions that stayed in one binade
     bool hit = false;
-    while (a < n) {
-        const double xn = x + c;
-        const double d = xn - x; // exact whenever xn and x share a binade
-        const int e = expo(xn);
-        inb = (e == expo(x)) ? inb + 1 : 0;
-        x = xn;
-        a++;
-        if (stop_hit<STOP>(x, thr)) { hit = true; break; }
-        if (inb >= 2 && a < n && e > 0 && e < 2046) {
-            // steady state: jump m additions that stay strictly inside the binade
-            // and strictly before the stop
-            // `lim` bounds the jumped results: they must stay inside the binade and
-            // before the stop.  Going down, the binade bottom 2^e itself is excluded:
-            // a steady step that lands exactly on 2^e means the exact difference lies
-            // just below it, in the finer grid of the next binade, so that step has to
-            // be a real subtraction.
-            double lim;
-            bool strict = true;  // results must be strictly beyond lim (else: may equal it)
-            double mf;
-            if (STOP == STOP_GE) {
-                lim = pow2_biased(e + 1);           // results stay < 2^(e+1) ...
-                if (thr < lim) lim = thr;           // ... and < thr
-                mf = (lim - x) / d;
-            } else {
-                lim = pow2_biased(e);               // results stay > 2^e ...
-                if (STOP == STOP_LE) { if (thr >= lim) lim = thr; }              // ... and > thr
-                else if (thr > lim) { lim = thr; strict = false; }               // ... and >= thr
-                mf = (x - lim) / (-d);
-            }
-            // clamp before converting (mf may be huge or, from rounding, slightly negative)
-            const double cap = (double)(n - a);
-            if (!(mf > 0.0)) mf = 0.0;
-            if (mf > cap) mf = cap;
-            int32_t m = (int32_t)mf;               // floor for mf >= 0
-            // exact corrections: x + m*d is exact while it stays inside the binade
-            if (STOP == STOP_GE) {
-                while (m > 0 && !(x + (double)m * d < lim)) m--;
-                while (m < n - a && (x + (double)(m + 1) * d < lim)) m++;
-            } else if (strict) {
-                while (m > 0 && !(x + (double)m * d > lim)) m--;
-                while (m < n - a && (x + (double)(m + 1) * d > lim)) m++;
-            } else {
-                while (m > 0 && !(x + (double)m * d >= lim)) m--;
-                while (m < n - a && (x + (double)(m + 1) * d >= lim)) m++;
-            }
-            x = x + (double)m * d;
-            a += m;
-        }
-    }
-    x_io = x;
+    while (a < n && !hit) a += chain_segment<STOP>(cs, c, thr, n - a, hit);
+    x_io = cs.x;
     a_out = a;
     return hit;
 }

@@ -133,23 +133,34 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
         s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
         ke = t.interval_tick[s.j + 1];
     }
-    double bw = s.trace[s.tpos];
+    // One flat loop over chain SEGMENTS (abr_exact_jump.h); a lane moves on to its next
+    // trace interval between two segments.  The next interval's bandwidth and end tick
+    // are loaded one interval ahead so the loads overlap the arithmetic.
     const int32_t lim = mt - s.k;
-    double dl = 0.0;
+    int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+    double c = s.trace[s.tpos] * kTickDt;     // bandwidth * dt, the product first  (:160)
+    double bw_next = s.trace[tn];
+    int32_t ke_next = t.interval_tick[s.j + 2];
+    ChainState cs;
+    cs.x = 0.0; cs.d = 0.0; cs.inb = 0;       // downloaded_size = 0 at a call site
     int32_t n_dl = 0, kk = s.k;
     bool hit = false;
     while (!hit && n_dl < lim) {
-        // prefetch the next interval while this one is integrated
-        const int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-        const double bw_next = s.trace[tn];
-        const int32_t ke_next = t.interval_tick[s.j + 2];
+        if (kk >= ke) {                       // interval over: its successor was prefetched
+            s.j++; s.tpos = tn;
+            c = bw_next * kTickDt;
+            ke = ke_next;
+            tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+            bw_next = s.trace[tn];
+            ke_next = t.interval_tick[s.j + 2];
+            cs.inb = 0;                       // new constant: the steady increment is void
+        }
         int32_t n = ke - kk;
         if (n > lim - n_dl) n = lim - n_dl;
-        int32_t adds = 0;
-        hit = chain<STOP_GE>(dl, bw * kTickDt, target, n, adds);             // :160-163
+        const int32_t adds = chain_segment<STOP_GE>(cs, c, target, n, hit);       // :160-163
         n_dl += adds; kk += adds;
-        if (!hit && kk >= ke) { s.j++; s.tpos = tn; bw = bw_next; ke = ke_next; }
     }
+    const double dl = cs.x;
     // ---- buffer side of the ticks before the completing one ----
     lanej_idle(s, t, hit ? n_dl - 1 : n_dl);
     if (!hit) { r.timeout = true; return r; }

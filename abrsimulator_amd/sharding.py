@@ -1,0 +1,87 @@
+"""Multi-GPU layout of a batched environment: contiguous lane shards, one process
+per GPU, no exchange inside a step, ONE collective per launch -- an all-gather of
+the (obs, reward) slabs (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+
+The reference has no distributed code at all; lanes are
+independent (no cross-lane term anywhere in Simulator.py:135-208 or mpc.py:120-162),
+so sharding is a partition of the lane index space.  The built-in random policy is
+counter-based on the GLOBAL lane id (abr_env_set_lane_id_base), so an N-shard run
+reproduces the 1-shard run lane for lane.
+"""
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_lanes: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """(first global lane, number of lanes) of `rank`; shards differ by at most one lane."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(total_lanes), int(world_size))
+    n = base + (1 if rank < rem else 0)
+    lane0 = rank * base + min(rank, rem)
+    return lane0, n
+
+
+def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int]):
+    """Deterministic global-lane -> (trace_id, start_offset) map used by bench.py:
+    lane i reads trace i % n_traces from offset (i * 2654435761 mod 2^32) % len."""
+    i = np.arange(lane0, lane0 + n, dtype=np.uint64)
+    lens = np.asarray(trace_lens, np.uint64)
+    tid = (i % np.uint64(len(lens))).astype(np.int32)
+    off = ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % lens[tid]).astype(np.int32)
+    return tid, off
+
+
+class ObsRewardGather:
+    """Double-buffered all-gather of (obs, reward) slabs, overlapped with the next
+    launch on a side stream when the tensors live on a GPU."""
+
+    def __init__(self, obs_shape, reward_shape, device, group=None, n_buffers=2):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        # flat [world * shape[0], ...] outputs: the concatenating form every backend accepts
+        self.obs_shape, self.reward_shape = tuple(obs_shape), tuple(reward_shape)
+        self.obs = [torch.empty((self.world * obs_shape[0],) + tuple(obs_shape[1:]),
+                                dtype=torch.float32, device=device) for _ in range(n_buffers)]
+        self.reward = [torch.empty((self.world * reward_shape[0],) + tuple(reward_shape[1:]),
+                                   dtype=torch.float32, device=device) for _ in range(n_buffers)]
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.pending = [None] * n_buffers
+
+    def wait_free(self, b):
+        """Before the producer overwrites source slab b again."""
+        if self.cuda and self.pending[b] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.pending[b])
+
+    def gather(self, b, obs, reward):
+        """Enqueue the all-gather of slab b (obs/reward are this rank's shard)."""
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                dist.all_gather_into_tensor(self.obs[b], obs, group=self.group)
+                dist.all_gather_into_tensor(self.reward[b], reward, group=self.group)
+                fin = torch.cuda.Event()
+                fin.record()
+            self.pending[b] = fin
+        else:
+            dist.all_gather_into_tensor(self.obs[b], obs, group=self.group)
+            dist.all_gather_into_tensor(self.reward[b], reward, group=self.group)
+        return (self.obs[b].view((self.world,) + self.obs_shape),
+                self.reward[b].view((self.world,) + self.reward_shape))
+
+    def finish(self):
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
+def unshard_lanes(gathered, counts):
+    """[world, ..., n_max] gathered slabs -> [..., total] in global lane order
+    (shards are contiguous, so this is a concatenation along the lane axis)."""
+    return torch.cat([gathered[r][..., :counts[r]] for r in range(len(counts))], dim=-1)

@@ -50,11 +50,14 @@ def synth_traces(mixed=False):
 
 
 def lane_assignment(lane0, n, traces):
-    i = np.arange(lane0, lane0 + n, dtype=np.uint64)
-    tid = (i % np.uint64(len(traces))).astype(np.int32)
-    lens = np.array([len(t) for t in traces], np.uint64)
-    off = ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % lens[tid]).astype(np.int32)
-    return tid, off
+    from abrsimulator_amd.sharding import lane_assignment as la
+    return la(lane0, n, [len(t) for t in traces])
+
+
+def host_cores():
+    """Threads for the CPU baseline: the GPU box exposes every host core in the affinity
+    mask but grants one GPU's share of CPU time (16 cores); ABR_BENCH_CORES overrides."""
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("ABR_BENCH_CORES", "16"))))
 
 
 def cpu_baseline_env(traces, seed, budget_s=12.0):
@@ -63,7 +66,7 @@ def cpu_baseline_env(traces, seed, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     cfg = O.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, INTERVAL, WEIGHTS, 1.0)
 
     def prep(lane0, n):
@@ -111,7 +114,7 @@ def cpu_baseline_mpc(budget_s=10.0):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     mc = O.mpc_cfg(len(LADDER), 5, V, L, MAX_BUFFER, 1.0, 4.3, 0.0)
     br = np.tile(np.array(LADDER), (V, 1))
     sz = br * L
@@ -194,20 +197,18 @@ def main():
                 for _ in range(2)]
         gather = world > 1 and not a.no_gather
         if gather:
-            # the one collective of the path: all-gather of (obs, reward), overlapped with the
-            # next launch on a side stream (double-buffered slabs)
-            comm = torch.cuda.Stream(dev)
-            g_obs = [torch.empty(world, F, OBS_DIM, N, dtype=torch.float32, device=dev) for _ in range(2)]
-            g_rew = [torch.empty(world, F, N, dtype=torch.float32, device=dev) for _ in range(2)]
-            pending = [None, None]
+            # the one collective of the path: all-gather of the (obs, reward) slabs on a side
+            # stream, overlapped with the next launch (double-buffered)
+            from abrsimulator_amd.sharding import ObsRewardGather
+            gat = ObsRewardGather((F, OBS_DIM, N), (F, N), dev)
 
         def run(n_steps, timed):
             left, it = n_steps, 0
             while left > 0:
                 f = min(F, left)
                 b = it & 1
-                if gather and pending[b] is not None:
-                    torch.cuda.current_stream(dev).wait_event(pending[b])   # slab b is free again
+                if gather:
+                    gat.wait_free(b)                      # slab b has been gathered: reusable
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 env.step_random(f, a.seed, out=bufs[b] if f == F else None)
@@ -215,17 +216,11 @@ def main():
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
                     ev.append((e0, e1, f))
                 if gather and f == F:
-                    done_ev = torch.cuda.Event(); done_ev.record()
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(done_ev)
-                        dist.all_gather_into_tensor(g_obs[b], bufs[b]["obs"])
-                        dist.all_gather_into_tensor(g_rew[b], bufs[b]["reward"])
-                        fin = torch.cuda.Event(); fin.record()
-                    pending[b] = fin
+                    gat.gather(b, bufs[b]["obs"], bufs[b]["reward"])
                 left -= f
                 it += 1
             if gather:
-                torch.cuda.current_stream(dev).wait_stream(comm)
+                gat.finish()
 
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"
@@ -280,7 +275,7 @@ def main():
         pts = 4.07 * (8 + 4)
         per_decision = 32 + 4 + 1 + 1 + 8 + pts
         alg_bytes = N * (2 * STATE_BYTES + f_per_launch * per_decision)
-        roof = dict(bound="hbm", kernel="env_advance_kernel<2>",
+        roof = dict(bound="hbm", kernel="env_jump_kernel<2>",
                     achieved=alg_bytes / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     traffic=None, avg_launch_us=avg_launch_s * 1e6,
                     algorithmic_bytes_per_launch=alg_bytes,
