@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -929,28 +930,54 @@ struct Best { double J; int32_t flat; };
 // same order as the reference forms them, so every leaf value is bit-identical
 // to a from-scratch evaluation.  Leaves are visited in increasing flat index;
 // strict `<` keeps the first minimum (numpy argmin on the raveled C-order grid).
-template <int LVL, int H>
-__device__ inline void mpc_dfs(const MpcLds &t, double q, double v, double rb, double buf,
-                               int prev_r, int32_t flat, Best &best) {
-    const double *brv = t.brv + LVL * t.B, *rbt = t.rbt + LVL * t.B, *tdl = t.tdl + LVL * t.B;
-    const double br_prev = brv[prev_r];
-    const bool leaf = (LVL == H - 1) || (LVL == t.heff - 1);
-    for (int r = 0; r < t.B; r++) {
-        const double b = brv[r];
-        const double q2 = q + b;                              // :146
-        const double v2 = v + fabs(b - br_prev);              // :148-149
-        const double rb2 = rb + (rbt[r] - buf);               // :151-152
-        const int32_t f2 = flat * t.B + r;
-        if (leaf) {
-            const double J = -((q2 - t.wv * v2) - t.wr * rb2);   // :158-162 (startup term is 0)
-            if (J < best.J) { best.J = J; best.flat = f2; }
-        } else {
-            if constexpr (LVL + 1 < H) {
-                const double tmp = pymax0(buf - tdl[r]);                       // :107,:116
-                const double wait = pymax0(tmp + t.L - t.max_buffer);          // :108-109
-                const double nb = pymax0(tmp + t.L - wait);                    // :117
-                mpc_dfs<LVL + 1, H>(t, q2, v2, rb2, nb, r, f2, best);
-            }
+//
+// BC > 0: the number of rates is a compile-time constant: the two innermost
+// levels are fully unrolled and the innermost level's tables (bl = bitrates,
+// rl = max(0,size,L)/C_hat) live in registers instead of LDS.  BC == 0: generic.
+template <int LVL, int H, int BC>
+__device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
+                                         int r, double q, double v, double rb, double buf,
+                                         double br_prev, int32_t flat, Best &best);
+
+template <int LVL, int H, int BC>
+__device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const double *rl,
+                                        double q, double v, double rb, double buf,
+                                        double br_prev, int32_t flat, Best &best) {
+    const int B = BC ? BC : t.B;
+    if constexpr (BC > 0 && LVL >= H - 2) {
+#pragma unroll
+        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+    }
+}
+
+template <int LVL, int H, int BC>
+__device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
+                                         int r, double q, double v, double rb, double buf,
+                                         double br_prev, int32_t flat, Best &best) {
+    const int B = BC ? BC : t.B;
+    constexpr bool kLast = (LVL == H - 1);
+    constexpr bool kRegs = kLast && (BC > 0);
+    const double b = kRegs ? bl[r] : t.brv[LVL * B + r];
+    const double rt = kRegs ? rl[r] : t.rbt[LVL * B + r];
+    const double q2 = q + b;                                  // :146
+    const double v2 = v + fabs(b - br_prev);                  // :148-149
+    const double rb2 = rb + (rt - buf);                       // :151-152
+    const int32_t f2 = flat * B + r;
+    const bool leaf = kLast || (LVL == t.heff - 1);
+    if (leaf) {
+        const double J = -((q2 - t.wv * v2) - t.wr * rb2);    // :158-162 (startup term is 0)
+        if (J < best.J) { best.J = J; best.flat = f2; }
+    } else {
+        if constexpr (LVL + 1 < H) {
+            const double tmp = pymax0(buf - t.tdl[LVL * B + r]);               // :107,:116
+            const double wait = pymax0(tmp + t.L - t.max_buffer);              // :108-109
+            const double nb = pymax0(tmp + t.L - wait);                        // :117
+            // bitrates[LVL+1][R[LVL+1]] of the child's "previous" digit r (both from chunk LVL+1's ladder)
+            const double bp = (LVL + 1 == H - 1 && BC > 0) ? bl[r] : t.brv[(LVL + 1) * B + r];
+            mpc_dfs<LVL + 1, H, BC>(t, bl, rl, q2, v2, rb2, nb, bp, f2, best);
         }
     }
 }
@@ -959,25 +986,26 @@ constexpr int kMpcLanesPerBlock = 16;
 
 // Threads of a block: (lane-in-block, prefix) pairs.  D = number of leading
 // levels fixed per thread (2 when H >= 3, else 1) -> T = B^D threads per lane.
-template <int H>
-__global__ void mpc_select_kernel(MpcParams p, int T, int D) {
+template <int H, int BC>
+__global__ __launch_bounds__(256, 4)
+void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     extern __shared__ double lds[];
-    const int B = p.B;
+    const int B = BC ? BC : p.B;
     const int HB = H * B;
     // layout per lane-in-block: brv[HB] rbt[HB] tdl[HB] pred[H] | then bestJ[T], bestF[T]
     const int per_lane = 3 * HB + H;
     double *tab = lds;
-    double *bestJ = lds + kMpcLanesPerBlock * per_lane;
-    int32_t *bestF = (int32_t *)(bestJ + kMpcLanesPerBlock * T);
-    __shared__ int32_t heff_s[kMpcLanesPerBlock];
+    double *bestJ = lds + LPB * per_lane;
+    int32_t *bestF = (int32_t *)(bestJ + LPB * T);
+    __shared__ int32_t heff_s[16];
 
     const int tid = threadIdx.x;
     const int li = tid / T;               // lane in block
     const int pre = tid - li * T;         // prefix id
-    const int64_t lane = (int64_t)blockIdx.x * kMpcLanesPerBlock + li;
-    const bool valid = (li < kMpcLanesPerBlock) && (lane < p.n_lanes) &&
+    const int64_t lane = (int64_t)blockIdx.x * LPB + li;
+    const bool valid = (li < LPB) && (lane < p.n_lanes) &&
                        !(p.mask && !p.mask[lane]);
-    double *my = tab + (li < kMpcLanesPerBlock ? li : 0) * per_lane;
+    double *my = tab + (li < LPB ? li : 0) * per_lane;
 
     // ---- phase 1: harmonic predictor, one thread per lane (mpc.py:81-93) ----
     if (valid && pre == 0) {
@@ -1048,16 +1076,24 @@ __global__ void mpc_select_kernel(MpcParams p, int T, int D) {
             }
         }
         if (ok) {
+            // innermost level's tables in registers (BC > 0)
+            double bl[BC ? BC : 1], rl[BC ? BC : 1];
+            if constexpr (BC > 0) {
+#pragma unroll
+                for (int r = 0; r < BC; r++) { bl[r] = t.brv[(H - 1) * B + r]; rl[r] = t.rbt[(H - 1) * B + r]; }
+            }
             if (is_leaf) {
                 best.J = -((q - t.wv * v) - t.wr * rb); best.flat = flat;
             } else if (D == 2) {
-                if constexpr (H >= 3) mpc_dfs<2, H>(t, q, v, rb, buf, prev_r, flat, best);
+                if constexpr (H >= 3)
+                    mpc_dfs<2, H, BC>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
             } else {
-                if constexpr (H >= 2) mpc_dfs<1, H>(t, q, v, rb, buf, prev_r, flat, best);
+                if constexpr (H >= 2)
+                    mpc_dfs<1, H, BC>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
             }
         }
     }
-    if (li < kMpcLanesPerBlock) { bestJ[li * T + pre] = best.J; bestF[li * T + pre] = best.flat; }
+    if (li < LPB) { bestJ[li * T + pre] = best.J; bestF[li * T + pre] = best.flat; }
     __syncthreads();
     // ---- phase 4: arg-min over the T prefixes of a lane (ascending prefix = ascending flat) ----
     if (valid && pre == 0) {
@@ -1093,14 +1129,29 @@ static int validate_mpc(const abr_mpc_config *c) {
     return ABR_OK;
 }
 
+template <int H, int BC>
+static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
+    // lanes per workgroup: as many as fit 256 threads (4 waves).  Measured on MI355X at B=6,H=5
+    // (T=36): 7 lanes/WG 319 us, 16 lanes/WG (9 waves) 481 us, 3 lanes/WG 365 us per 65 536 lanes.
+    int lpb = 256 / T;
+    if (lpb > kMpcLanesPerBlock) lpb = kMpcLanesPerBlock;
+    if (const char *e = getenv("ABR_MPC_LPB")) { int v = atoi(e); if (v >= 1 && v < lpb) lpb = v; }  // tuning knob
+    if (lpb < 1) lpb = 1;
+    const int threads = ((lpb * T + 63) / 64) * 64;
+    const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);
+    const size_t lds = lpb * per_lane + (size_t)lpb * T * (sizeof(double) + sizeof(int32_t));
+    const unsigned grid = (unsigned)((p.n_lanes + lpb - 1) / lpb);
+    hipLaunchKernelGGL((mpc_select_kernel<H, BC>), dim3(grid), dim3(threads), lds, st, p, T, D, lpb);
+}
+
+// compile-time rate count for the common ladders (6 and 4 rates) up to horizon 6
 template <int H>
 static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
-    const int threads = ((kMpcLanesPerBlock * T + 63) / 64) * 64;
-    const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);
-    const size_t lds = kMpcLanesPerBlock * per_lane +
-                       (size_t)kMpcLanesPerBlock * T * (sizeof(double) + sizeof(int32_t));
-    const unsigned grid = (unsigned)((p.n_lanes + kMpcLanesPerBlock - 1) / kMpcLanesPerBlock);
-    hipLaunchKernelGGL(mpc_select_kernel<H>, dim3(grid), dim3(threads), lds, st, p, T, D);
+    if constexpr (H <= 6) {
+        if (p.B == 6) { launch_mpc_b<H, 6>(p, T, D, st); return; }
+        if (p.B == 4) { launch_mpc_b<H, 4>(p, T, D, st); return; }
+    }
+    launch_mpc_b<H, 0>(p, T, D, st);
 }
 
 extern "C" int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,

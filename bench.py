@@ -283,12 +283,17 @@ def main():
                          "(SURVEY.md 8d); the HBM fraction is reported as mandated")
         roof["frac"] = roof["achieved"] / roof["peak"]
     else:
-        # K3 is fp64-VALU-bound: 99 flop per combo in the reference's formulation
-        flops = N * 6 ** 5 * 99.0
-        roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5>",
+        # K3 is fp64-VALU-bound.  Executed work with prefix sharing: 7 776 leaves x
+        # 9 flop + 1 554 inner nodes x 13 flop = 90.2 kflop per lane decision (the reference's
+        # from-scratch formulation is 99 flop x 7 776 combos = 770 kflop).  No FMA may
+        # be used (-ffp-contract=off is the parity contract), so 50 % of the FMA peak is the ceiling.
+        flops = N * (7776 * 9.0 + 1554 * 13.0)
+        roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5,6>",
                     achieved=flops / avg_launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                     traffic=None, avg_launch_us=avg_launch_s * 1e6,
-                    note="99 fp64 flop/combo on the 7 776-combo basis; prefix sharing executes fewer")
+                    reference_formulation_tflops=N * 6 ** 5 * 99.0 / avg_launch_s / 1e12,
+                    note="executed fp64 flop (prefix-sharing DFS) against the FMA peak; "
+                         "add/mul only, so 0.5 is the ceiling")
         roof["frac"] = roof["achieved"] / roof["peak"]
     tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tj):

@@ -83,7 +83,7 @@ def test_sweeps_match_reference_goldens(name):
 
 
 @pytest.mark.parametrize("B,H,N", [(6, 5, 4096), (4, 5, 1000), (6, 3, 513), (3, 2, 100), (5, 4, 300),
-                                   (2, 8, 64), (16, 2, 50), (7, 6, 40)])
+                                   (2, 8, 64), (16, 2, 50), (7, 6, 40), (16, 3, 20), (12, 4, 12), (4, 6, 200), (6, 6, 50), (6, 2, 300)])
 def test_select_matches_oracle_seeded(oracle, B, H, N):
     rng = np.random.default_rng(B * 100 + H)
     V, L, mb = 40, 4.0, 20.0
