@@ -85,76 +85,107 @@ struct ChainState {
     int32_t inb;   // consecutive additions that stayed in one binade
 };
 
+// Is a jumped result y on the allowed side of lim?
+template <int STOP>
+ABR_HD bool jump_inside(double y, double lim, bool strict) {
+    if (STOP == STOP_GE) return y < lim;
+    return strict ? (y > lim) : (y >= lim);
+}
+
+// Slow exact search for the jump length; only reached when the reciprocal estimate
+// was off by more than one (astronomically long jumps).  Kept out of line so that
+// the hot path stays small.
+template <int STOP>
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#else
+inline
+#endif
+int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t room) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    while (m > 0 && !jump_inside<STOP>(x + (double)m * d, lim, strict)) m--;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    while (m < room && jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict)) m++;
+    return m;
+}
+
 // One SEGMENT of a chain: up to three real additions (the one that may cross a
 // binade plus the two that establish the steady increment) followed by one exact
 // jump to the end of the binade / just before the stop / the end of the budget.
 // Performs at most n additions; returns how many (>= 1 when n >= 1) and sets
 // `hit` when the last addition satisfied the STOP predicate.
-// Straight-line and predicated on purpose: this is the body of the GPU hot loop.
+// Straight-line selects on purpose: this is the body of the GPU hot loop.
 template <int STOP>
-ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit) {
+ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit_out) {
     double x = cs.x, d = cs.d;
     int32_t inb = cs.inb, a = 0;
-    hit = false;
+    bool hit = false;
     // ---- up to three real additions ----
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int s = 0; s < 3; s++) {
-        const bool go = (a < n) && !hit && (s == 0 || inb < 2);
+        const bool go = (a < n) & !hit & ((s == 0) | (inb < 2));
         const double xn = x + c;
         const double dn = xn - x;        // exact whenever xn and x share a binade
         const bool same = expo(xn) == expo(x);
-        if (go) {
-            inb = same ? inb + 1 : 0;
-            d = dn;
-            x = xn;
-            a++;
-            hit = stop_hit<STOP>(x, thr);
-        }
+        inb = go ? (same ? inb + 1 : 0) : inb;
+        d = go ? dn : d;
+        x = go ? xn : x;
+        a += go ? 1 : 0;
+        hit = go ? stop_hit<STOP>(xn, thr) : hit;
     }
     // ---- one exact jump in the steady state ----
     const int e = expo(x);
-    if (!hit && inb >= 2 && a < n && e > 0 && e < 2046) {
+    const bool can = !hit & (inb >= 2) & (a < n) & (e > 0) & (e < 2046);
+    {
         // `lim` bounds the jumped results: they must stay inside the binade and before
         // the stop.  Going down, the binade bottom 2^e itself is excluded: a steady step
         // that lands exactly on 2^e means the exact difference lies just below it, on the
         // finer grid of the next binade, so that step has to be a real subtraction.
+        const int ec = (e > 0 && e < 2046) ? e : 1;       // keep pow2_biased in range when !can
         double lim, gap;
         bool strict = true;              // results strictly beyond lim (else: may equal it)
         if (STOP == STOP_GE) {
-            lim = pow2_biased(e + 1);               // results stay < 2^(e+1) ...
-            if (thr < lim) lim = thr;               // ... and < thr
+            const double top = pow2_biased(ec + 1);  // results stay < 2^(e+1) ...
+            lim = (thr < top) ? thr : top;           // ... and < thr
             gap = lim - x;
         } else {
-            lim = pow2_biased(e);                   // results stay > 2^e ...
-            if (STOP == STOP_LE) { if (thr >= lim) lim = thr; }                  // ... and > thr
-            else if (thr > lim) { lim = thr; strict = false; }                   // ... and >= thr
+            const double bot = pow2_biased(ec);      // results stay > 2^e ...
+            if (STOP == STOP_LE) {
+                lim = (thr >= bot) ? thr : bot;      // ... and > thr
+            } else {
+                strict = !(thr > bot);               // ... and >= thr
+                lim = (thr > bot) ? thr : bot;
+            }
             gap = x - lim;
         }
         const double ad = (STOP == STOP_GE) ? d : -d;
+        const int32_t room = can ? (n - a) : 0;
         double mf = gap * rcp_est(ad);
-        const double cap = (double)(n - a);
-        if (!(mf > 0.0)) mf = 0.0;
-        if (mf > cap) mf = cap;
+        const double cap = (double)room;
+        mf = (mf > 0.0) ? mf : 0.0;      // also maps NaN to 0
+        mf = (mf > cap) ? cap : mf;
         int32_t m = (int32_t)mf;
-        // exact corrections (x + m*d is exact while it stays inside the binade); the
-        // estimate is off by at most one except for astronomically long jumps
-        const int32_t room = n - a;
-        if (STOP == STOP_GE) {
-            while (m > 0 && !(x + (double)m * d < lim)) m--;
-            while (m < room && (x + (double)(m + 1) * d < lim)) m++;
-        } else if (strict) {
-            while (m > 0 && !(x + (double)m * d > lim)) m--;
-            while (m < room && (x + (double)(m + 1) * d > lim)) m++;
-        } else {
-            while (m > 0 && !(x + (double)m * d >= lim)) m--;
-            while (m < room && (x + (double)(m + 1) * d >= lim)) m++;
-        }
-        x = x + (double)m * d;
+        // exact corrections (x + m*d is exact while it stays inside the binade): the
+        // estimate is within one of the answer, so one step down and one step up settle it
+        const bool ok0 = (m == 0) | jump_inside<STOP>(x + (double)m * d, lim, strict);
+        m -= ok0 ? 0 : 1;
+        const bool up = (m < room) & jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict);
+        m += up ? 1 : 0;
+        // verify; the out-of-line search only runs if the estimate was off by more than one
+        const bool fine = ((m == 0) | jump_inside<STOP>(x + (double)m * d, lim, strict)) &
+                          !((m < room) & jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict));
+        if (!fine) m = jump_fix<STOP>(x, d, lim, strict, m, room);
+        x = x + (double)m * d;           // m == 0 when !can
         a += m;
     }
     cs.x = x; cs.d = d; cs.inb = inb;
+    hit_out = hit;
     return a;
 }
 
