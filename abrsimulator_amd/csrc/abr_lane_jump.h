@@ -33,6 +33,7 @@
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
+constexpr int kPrologue = 32;       // plain additions at the start of a download (see lanej_step)
 
 struct Tables {
     const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
@@ -145,6 +146,20 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
     cs.x = 0.0; cs.d = 0.0; cs.inb = 0;       // downloaded_size = 0 at a call site
     int32_t n_dl = 0, kk = s.k;
     bool hit = false;
+    {
+        // Prologue: downloaded_size starts at 0, so its first additions cross a binade
+        // every 1, 2, 4, 8, ... steps, where a jump buys nothing.  Do the first
+        // kPrologue additions as plain additions (that IS the reference's sequence) and
+        // keep them only if they all fit the first interval and stay below the target
+        // (the sequence is increasing, so no earlier one can have reached it).
+        double x = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < kPrologue; i++) x = x + c;
+        const bool use = (ke - kk >= kPrologue) && (lim >= kPrologue) && (x < target);
+        if (use) { cs.x = x; n_dl = kPrologue; kk += kPrologue; }
+    }
     while (!hit && n_dl < lim) {
         if (kk >= ke) {                       // interval over: its successor was prefetched
             s.j++; s.tpos = tn;

@@ -248,3 +248,42 @@ def test_full_size_properties():
     q = env.episode_qoe()
     lat = env.observe_f64()["average_latency"]
     assert torch.allclose(out["reward"].double().sum(0) + 0.1 * lat, q, rtol=2e-5, atol=1e-3)
+
+
+def test_simulator_class_runs_reference_style_script(tmp_path):
+    """The reference's own call sequence (Simulator.py:46-93) on files on disk, with a
+    plugin that keeps get_next_bitrate's signature; result == the golden run() values."""
+    import abrsimulator_amd as A
+    m, g = load_golden("env_const_policy")
+    N, V = g["actions"].shape
+    paths = []
+    for t, tr in enumerate(g["traces"]):
+        p = str(tmp_path / f"trace{t}.txt")
+        A.save_trace_file(p, tr)
+        paths.append(p)
+    mpdfile = str(tmp_path / "video.mpd")
+    A.save_mpd_file(mpdfile, [m["ladder"]] * V)
+    acts = torch.from_numpy(g["actions"]).cuda()
+    seen = []
+
+    class Replay:
+        def get_next_bitrate(self, chunk_id, previous_bitrates, previous_bandwidths, buffer_level):
+            c = int(chunk_id[0])
+            seen.append((c, buffer_level.clone(), previous_bandwidths[:c].clone()))
+            return acts[:, c]
+
+    class Speed:
+        def get_next_speed(self):
+            return m["speed"]
+
+    sim = A.Simulator(Replay(), Speed(), n_lanes=N)
+    sim.set_qoe_metric(A.QOEMetric(*m["weights"]))
+    sim.set_network_info(m["interval"], paths)
+    sim.set_mpd(m["chunk_length"], m["max_buffer"], m["start_up_length"], mpdfile)
+    sim.set_lanes(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
+    qoe = sim.run().cpu().numpy()
+    assert np.allclose(qoe, g["final_qoe"], rtol=1e-10)
+    for c, buf, bws in seen:
+        assert np.array_equal(buf.cpu().numpy(), g["buffer_level"][:, c])
+        if c:
+            assert np.array_equal(bws.cpu().numpy().T, g["final_bandwidths"][:, :c])

@@ -1,0 +1,37 @@
+"""File formats of the reference (8f rank 2): the trace loader is the reference's
+own (one float per line); the MPD loader is the repaired intent of a parser that
+raises TypeError in the reference (D4)."""
+import numpy as np
+import pytest
+
+
+def test_trace_file_roundtrip_is_bit_exact(tmp_path):
+    import abrsimulator_amd as A
+    rng = np.random.default_rng(0)
+    vals = list(rng.uniform(0.1, 9.0, 500)) + [1.0, 0.1, 1e-3, 123456.789, float(np.float32(3.3))]
+    p = str(tmp_path / "t.txt")
+    A.save_trace_file(p, vals)
+    back = A.load_trace_file(p)
+    assert back == [float(v) for v in vals]                 # exact float64 equality
+    # what the reference does: float(line) per line (Simulator.py:62-63)
+    assert back == [float(line) for line in open(p).readlines()]
+    net = A.load_network_info(0.5, [p, p])
+    assert net.interval == 0.5 and len(net.bandwidths) == 2
+    with pytest.raises(ValueError):
+        open(str(tmp_path / "e.txt"), "w").close()
+        A.load_trace_file(str(tmp_path / "e.txt"))
+
+
+def test_mpd_file(tmp_path):
+    import abrsimulator_amd as A
+    lads = [[0.3, 0.75, 1.2], [0.31, 0.8, 1.25], [0.29, 0.7, 1.1]]
+    p = str(tmp_path / "v.mpd")
+    A.save_mpd_file(p, lads)
+    mpd = A.load_mpd_file(4, 20, 8, p)
+    assert mpd.video_length == 3 and mpd.chunk_length == 4 and mpd.max_buffer == 20
+    assert [list(c.bitrates) for c in mpd.chunks] == lads
+    assert list(mpd.chunks[1].sizes) == [b * 4 for b in lads[1]]
+    assert mpd.ladder() == lads[0]
+    open(p, "a").write("1 2\n")
+    with pytest.raises(ValueError):
+        A.load_mpd_file(4, 20, 8, p)
