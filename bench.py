@@ -141,9 +141,9 @@ def cpu_baseline_mpc(budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=960)
-    ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--fuse", type=int, default=16, help="chunk decisions per kernel launch")
+    ap.add_argument("--steps", type=int, default=4800)
+    ap.add_argument("--warmup", type=int, default=480)
+    ap.add_argument("--fuse", type=int, default=48, help="chunk decisions per kernel launch (48 = one episode)")
     ap.add_argument("--lanes-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
@@ -197,10 +197,13 @@ def main():
                 for _ in range(2)]
         gather = world > 1 and not a.no_gather
         if gather:
-            # the one collective of the path: all-gather of the (obs, reward) slabs on a side
-            # stream, overlapped with the next launch (double-buffered)
+            # the one collective of the path: per launch, all-gather of (obs, reward) on a side
+            # stream, overlapped with the next launch (double-buffered).  obs = the observation
+            # every lane ends the launch with (what an off-GPU policy needs to act next; the
+            # intermediate observations of a fused launch are consumed on-device by the built-in
+            # policy and stay in the local slab); reward = all F per-step rewards.
             from abrsimulator_amd.sharding import ObsRewardGather
-            gat = ObsRewardGather((F, OBS_DIM, N), (F, N), dev)
+            gat = ObsRewardGather((OBS_DIM, N), (F, N), dev)
 
         def run(n_steps, timed):
             left, it = n_steps, 0
@@ -216,7 +219,7 @@ def main():
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
                     ev.append((e0, e1, f))
                 if gather and f == F:
-                    gat.gather(b, bufs[b]["obs"], bufs[b]["reward"])
+                    gat.gather(b, bufs[b]["obs"][F - 1], bufs[b]["reward"])
                 left -= f
                 it += 1
             if gather:
@@ -322,7 +325,8 @@ def main():
                        "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
                        "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
                        "auto_reset": True,
-                       "collective": ("all_gather(obs,reward)" if world > 1 and not a.no_gather
+                       "collective": ("all_gather(final obs [8,N] + rewards [fuse,N]) per launch, "
+                                      "overlapped" if world > 1 and not a.no_gather
                                       and a.workload == "env_random" else "none")},
             "roofline": roof, "cpu_baseline": cpu,
         }
