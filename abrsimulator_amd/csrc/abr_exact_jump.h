@@ -12,15 +12,17 @@
 //     fl(x + c) = (X + q)*u        if r <  u/2
 //               = (X + q + 1)*u    if r >  u/2
 //               = the even one     if r == u/2,
-// i.e. a constant integer increment D, except that in the tie case D depends on
-// the parity of X + q -- and a tie always produces an even X, so from the second
-// consecutive in-binade step on D is constant there too.  Hence:
-//     once two consecutive additions have stayed inside one binade, every
-//     further in-binade addition adds exactly d = (last result) - (previous one),
-//     and x + m*d is computed exactly in float64 (all terms are multiples of u
-//     below 2^53 * u).
-// The same holds for a negative constant.  Steps that leave the binade, and the
-// first two steps inside a new one, are executed as real additions.
+// i.e. a constant integer increment D = RNE(c/u) whatever X is -- except in the tie
+// case, where the first step depends on the parity of X + q; a tie always produces
+// an even X, so from the second in-binade step on D is the constant q + (q odd)
+// there too, which is again RNE(c/u).  D*u is obtained without touching x:
+//     d = fl(2^e + |c|) - 2^e        (2^e has an even mantissa; needs |c| < 2^e)
+// and c - d is computed exactly, so "tie" is the test |c - d| == u/2.  Hence:
+//     inside one binade every addition adds exactly d (after one real in-binade
+//     addition in the tie case), and x + m*d is computed exactly in float64 (all
+//     terms are multiples of u below 2^53 * u).
+// The same holds for a negative constant.  Steps that leave the binade are executed
+// as real additions.
 //
 // This header is plain C++ (host + device) so that tests/ can fuzz it on the CPU
 // against the naive loop.  Compile with -ffp-contract=off.
@@ -113,41 +115,34 @@ int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t
     return m;
 }
 
-// One SEGMENT of a chain: up to three real additions (the one that may cross a
-// binade plus the two that establish the steady increment) followed by one exact
-// jump to the end of the binade / just before the stop / the end of the budget.
-// Performs at most n additions; returns how many (>= 1 when n >= 1) and sets
-// `hit` when the last addition satisfied the STOP predicate.
+// One SEGMENT of a chain: one exact jump to the end of the binade / just before
+// the stop / the end of the budget, then one real addition (the one that crosses
+// the binade or satisfies the stop).  Performs at most n additions; returns how
+// many (>= 1 when n >= 1) and sets `hit` when the last one satisfied the STOP
+// predicate.  cs.inb counts the real in-binade additions just performed (only the
+// tie case needs one before it may jump); a caller that changes c resets it to 0.
 // Straight-line selects on purpose: this is the body of the GPU hot loop.
 template <int STOP>
 ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit_out) {
-    double x = cs.x, d = cs.d;
+    double x = cs.x;
     int32_t inb = cs.inb, a = 0;
-    bool hit = false;
-    // ---- up to three real additions ----
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int s = 0; s < 3; s++) {
-        const bool go = (a < n) & !hit & ((s == 0) | (inb < 2));
-        const double xn = x + c;
-        const double dn = xn - x;        // exact whenever xn and x share a binade
-        const bool same = expo(xn) == expo(x);
-        inb = go ? (same ? inb + 1 : 0) : inb;
-        d = go ? dn : d;
-        x = go ? xn : x;
-        a += go ? 1 : 0;
-        hit = go ? stop_hit<STOP>(xn, thr) : hit;
-    }
-    // ---- one exact jump in the steady state ----
     const int e = expo(x);
-    const bool can = !hit & (inb >= 2) & (a < n) & (e > 0) & (e < 2046);
+    const bool normal = (e > 54) & (e < 2046);
+    const int ec = normal ? e : 1000;                // keep the bit tricks in range when unused
+    const double ac = (c < 0.0) ? -c : c;
+    // steady increment of this binade and the tie test (header comment)
+    const double base = pow2_biased(ec);
+    const double dm = (base + ac) - base;            // RNE(|c| / u) * u
+    const double rem = ac - dm;                      // exact, in [-u/2, u/2]
+    const double half_u = pow2_biased(ec - 53);
+    const bool tie = ((rem < 0.0) ? -rem : rem) == half_u;
+    const bool can = normal & (n > 0) & (expo(ac) < e) & (!tie | (inb >= 1));
+    const double d = (STOP == STOP_GE) ? dm : -dm;
     {
         // `lim` bounds the jumped results: they must stay inside the binade and before
         // the stop.  Going down, the binade bottom 2^e itself is excluded: a steady step
         // that lands exactly on 2^e means the exact difference lies just below it, on the
         // finer grid of the next binade, so that step has to be a real subtraction.
-        const int ec = (e > 0 && e < 2046) ? e : 1;       // keep pow2_biased in range when !can
         double lim, gap;
         bool strict = true;              // results strictly beyond lim (else: may equal it)
         if (STOP == STOP_GE) {
@@ -155,36 +150,45 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
             lim = (thr < top) ? thr : top;           // ... and < thr
             gap = lim - x;
         } else {
-            const double bot = pow2_biased(ec);      // results stay > 2^e ...
             if (STOP == STOP_LE) {
-                lim = (thr >= bot) ? thr : bot;      // ... and > thr
+                lim = (thr >= base) ? thr : base;    // results stay > 2^e and > thr
             } else {
-                strict = !(thr > bot);               // ... and >= thr
-                lim = (thr > bot) ? thr : bot;
+                strict = !(thr > base);              // ... and >= thr
+                lim = (thr > base) ? thr : base;
             }
             gap = x - lim;
         }
-        const double ad = (STOP == STOP_GE) ? d : -d;
-        const int32_t room = can ? (n - a) : 0;
-        double mf = gap * rcp_est(ad);
+        const int32_t room = can ? n : 0;
+        double mf = gap * rcp_est(dm);
         const double cap = (double)room;
         mf = (mf > 0.0) ? mf : 0.0;      // also maps NaN to 0
         mf = (mf > cap) ? cap : mf;
         int32_t m = (int32_t)mf;
         // exact corrections (x + m*d is exact while it stays inside the binade): the
         // estimate is within one of the answer, so one step down and one step up settle it
-        const bool ok0 = (m == 0) | jump_inside<STOP>(x + (double)m * d, lim, strict);
+        const double y0 = x + (double)m * d;
+        const bool ok0 = (m == 0) | jump_inside<STOP>(y0, lim, strict);
         m -= ok0 ? 0 : 1;
-        const bool up = (m < room) & jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict);
+        const double y1 = x + (double)(m + 1) * d;
+        const bool up = (m < room) & jump_inside<STOP>(y1, lim, strict);
         m += up ? 1 : 0;
         // verify; the out-of-line search only runs if the estimate was off by more than one
-        const bool fine = ((m == 0) | jump_inside<STOP>(x + (double)m * d, lim, strict)) &
+        const double ym = x + (double)m * d;
+        const bool fine = ((m == 0) | jump_inside<STOP>(ym, lim, strict)) &
                           !((m < room) & jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict));
         if (!fine) m = jump_fix<STOP>(x, d, lim, strict, m, room);
-        x = x + (double)m * d;           // m == 0 when !can
-        a += m;
+        x = fine ? ym : (x + (double)m * d);         // m == 0 when !can
+        a = m;
     }
-    cs.x = x; cs.d = d; cs.inb = inb;
+    // ---- one real addition ----
+    const bool go = a < n;
+    const double xn = x + c;
+    const bool same = expo(xn) == expo(x);
+    inb = go ? (same ? inb + 1 : 0) : inb;
+    const bool hit = go & stop_hit<STOP>(xn, thr);
+    x = go ? xn : x;
+    a += go ? 1 : 0;
+    cs.x = x; cs.inb = inb;
     hit_out = hit;
     return a;
 }
