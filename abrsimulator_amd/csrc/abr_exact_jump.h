@@ -163,21 +163,24 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
         const double cap = (double)room;
         mf = (mf > 0.0) ? mf : 0.0;      // also maps NaN to 0
         mf = (mf > cap) ? cap : mf;
-        int32_t m = (int32_t)mf;
-        // exact corrections (x + m*d is exact while it stays inside the binade): the
-        // estimate is within one of the answer, so one step down and one step up settle it
-        const double y0 = x + (double)m * d;
-        const bool ok0 = (m == 0) | jump_inside<STOP>(y0, lim, strict);
-        m -= ok0 ? 0 : 1;
-        const double y1 = x + (double)(m + 1) * d;
-        const bool up = (m < room) & jump_inside<STOP>(y1, lim, strict);
-        m += up ? 1 : 0;
-        // verify; the out-of-line search only runs if the estimate was off by more than one
-        const double ym = x + (double)m * d;
-        const bool fine = ((m == 0) | jump_inside<STOP>(ym, lim, strict)) &
-                          !((m < room) & jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict));
+        const int32_t m0 = (int32_t)mf;
+        // Exact settlement (x + m*d is exact while it stays inside the binade).  The
+        // estimate is within one of the answer, so the answer is among base..base+2 with
+        // base = m0 - 1; the four candidates base..base+3 are evaluated independently
+        // (short dependency chain) and also prove the bracket: candidate 0 must be inside
+        // and candidate 3 outside, else the out-of-line exact search takes over.
+        const int32_t bs = (m0 > 0) ? m0 - 1 : 0;
+        const bool t0 = (bs == 0) | jump_inside<STOP>(x + (double)bs * d, lim, strict);
+        const double y1 = x + (double)(bs + 1) * d;
+        const double y2 = x + (double)(bs + 2) * d;
+        const double y3 = x + (double)(bs + 3) * d;
+        const bool t1 = (bs + 1 <= room) & jump_inside<STOP>(y1, lim, strict);
+        const bool t2 = (bs + 2 <= room) & jump_inside<STOP>(y2, lim, strict) & t1;
+        const bool t3 = (bs + 3 <= room) & jump_inside<STOP>(y3, lim, strict) & t2;
+        int32_t m = bs + (t1 ? 1 : 0) + (t2 ? 1 : 0);
+        const bool fine = t0 & !t3;
         if (!fine) m = jump_fix<STOP>(x, d, lim, strict, m, room);
-        x = fine ? ym : (x + (double)m * d);         // m == 0 when !can
+        x = x + (double)m * d;           // m == 0 when !can
         a = m;
     }
     // ---- one real addition ----
