@@ -161,15 +161,20 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
         if (use) { cs.x = x; n_dl = kPrologue; kk += kPrologue; }
     }
     while (!hit && n_dl < lim) {
-        if (kk >= ke) {                       // interval over: its successor was prefetched
-            s.j++; s.tpos = tn;
-            c = bw_next * kTickDt;
-            ke = ke_next;
-            tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-            bw_next = s.trace[tn];
-            ke_next = t.interval_tick[s.j + 2];
-            cs.inb = 0;                       // new constant: the steady increment is void
-        }
+        // Interval over?  Its successor was prefetched.  Branch-free on purpose, and the
+        // prefetch of the interval after that is (re)issued in EVERY trip: a load inside
+        // a divergent `if` must be waited for at the end of that `if` (the loaded
+        // registers merge with the not-taken path), exposing its full latency; issued
+        // unconditionally it is only needed one trip later.
+        const bool adv = kk >= ke;
+        c = adv ? bw_next * kTickDt : c;
+        ke = adv ? ke_next : ke;
+        s.j += adv ? 1 : 0;
+        s.tpos = adv ? tn : s.tpos;
+        cs.inb = adv ? 0 : cs.inb;            // new constant: the steady state is void
+        tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+        bw_next = s.trace[tn];
+        ke_next = t.interval_tick[s.j + 2];
         int32_t n = ke - kk;
         if (n > lim - n_dl) n = lim - n_dl;
         const int32_t adds = chain_segment<STOP_GE>(cs, c, target, n, hit);       // :160-163
