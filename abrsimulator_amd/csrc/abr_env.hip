@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
     uint8_t done = 0;
     int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0;
     double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
+    double g_su_obs = 0.0, g_rb_obs = 0.0;    // G[n_su_obs], G[n_rb_obs] carried in registers
 
     if (in_range) {
         if (MODE == 0) {
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
             lanej_load(s, p, i);
             n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
             last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+            g_su_obs = p.G[n_su_obs]; g_rb_obs = p.G[n_rb_obs];
             if (done) active = false;
         }
     }
@@ -545,6 +547,9 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
             const int64_t o = (int64_t)step * p.n_lanes + i;
             float *obs = obs_out ? obs_out + (int64_t)step * ABR_OBS_DIM * p.n_lanes : nullptr;
             if (active) {
+                // one burst of loads for everything the step needs (issued before the
+                // policy arithmetic so that the two overlap)
+                const abrx::StepStart st = abrx::lanej_begin_step(s, tb);
                 // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
                 int32_t a;
                 if (MODE == 1) a = actions[i];
@@ -561,8 +566,8 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                 } else {
                     const int32_t prev_action = s.last_action;
                     const int32_t chunk = s.chunk_id;
-                    const abrx::StepResult r =
-                        abrx::lanej_step(s, tb, p.ladder[a] * p.chunk_length /* :156 */, a);
+                    const abrx::StepResult r = abrx::lanej_download_and_wait(
+                        s, tb, st, p.ladder[a] * p.chunk_length /* :156 */, a);
                     double var = 0.0;
                     if (r.hit) {
                         const int64_t h = (int64_t)chunk * p.n_lanes + i;
@@ -574,13 +579,14 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                         if (prev_action >= 0) var = fabs(p.ladder[a] - p.ladder[prev_action]);
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
-                    const double rew = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
-                                       p.ws * (p.G[s.n_su] - p.G[n_su_obs]) + p.wv * var;
+                    const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
+                    const double rew = p.wr * (g_rb - g_rb_obs) + p.ws * (g_su - g_su_obs) + p.wv * var;
                     if (r.ended) done |= ABR_DONE_EPISODE;
                     if (r.timeout) done |= ABR_DONE_TIMEOUT;
                     if (reward_out) reward_out[o] = (float)rew;
                     if (done_out) done_out[o] = done;
                     n_su_obs = s.n_su; n_rb_obs = s.n_rb;
+                    g_su_obs = g_su; g_rb_obs = g_rb;
                     if (r.ended || r.timeout) {
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                                     p.action_hist[(int64_t)c * p.n_lanes + i];
                             abrx::lanej_init(s, tb, offset0);
                             episode_no++;
-                            n_su_obs = 0; n_rb_obs = 0;
+                            n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
                             last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
                             done = 0;
                             if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
@@ -709,7 +715,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     size_t N = (size_t)n_lanes, V = (size_t)c->video_length;
     L->G = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
     L->GP = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
-    L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 2), A);
+    L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 8), A);
     L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
     L->f64_state = o; o = align_up(o + sizeof(double) * 4 * N, A);
     L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);

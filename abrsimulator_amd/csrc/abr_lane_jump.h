@@ -121,27 +121,91 @@ struct StepResult {
     bool timeout;     // ran into max_ticks
 };
 
-// One decision: from a call site, download a chunk of target_size, then run to
-// the next call site.  `action` only labels the step (last_action).
-ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t action) {
+// Everything a step needs from memory before it can start, fetched in ONE burst of
+// independent loads (a lane alone on its SIMD cannot hide a chain of dependent loads):
+// phase B moved k only, so the trace cursor (j, tpos) may be up to kCatch intervals
+// behind; the candidates for all those cases are loaded at once and selected in
+// registers.  The caller can issue this before it computes the action.
+constexpr int kCatch = 4;
+struct StepStart {
+    double c;          // bandwidth * dt of the interval the call site is in (:160)
+    double bw_next;    // bandwidth of the next interval
+    int32_t ke;        // end tick of the current interval
+    int32_t ke_next;   // end tick of the next one
+    int32_t tn;        // trace position of the next interval
+    int32_t avail_next;// avail_tick[chunk_id + 1]: when the chunk after this one can start (:143)
+};
+
+ABR_HD int32_t trace_wrap(int32_t pos, int32_t tlen) {
+    if (pos >= tlen) pos -= tlen;
+    if (pos >= tlen) pos %= tlen;             // traces shorter than the look-ahead
+    return pos;
+}
+
+ABR_HD StepStart lanej_begin_step(LaneJ &s, const Tables &t) {
+    int32_t ke[kCatch + 2];
+    double bw[kCatch + 2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < kCatch + 2; i++) {
+        ke[i] = t.interval_tick[s.j + 1 + i];
+        bw[i] = s.trace[trace_wrap(s.tpos + i, s.tlen)];
+    }
+    StepStart st;
+    st.avail_next = t.avail_tick[s.chunk_id + 1];
+    // intervals the cursor is behind: ke[] is non-decreasing
+    int32_t adv = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < kCatch; i++) adv += (s.k >= ke[i]) ? 1 : 0;
+    if (adv == kCatch && s.k >= ke[kCatch]) {
+        // more than kCatch intervals behind (a long buffer_full wait): walk, then reload
+        s.j += kCatch; s.tpos = trace_wrap(s.tpos + kCatch, s.tlen);
+        int32_t e = t.interval_tick[s.j + 1];
+        while (s.k >= e) {
+            s.j++;
+            s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+            e = t.interval_tick[s.j + 1];
+        }
+        st.ke = e; st.ke_next = t.interval_tick[s.j + 2];
+        st.tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+        st.c = s.trace[s.tpos] * kTickDt; st.bw_next = s.trace[st.tn];
+        return st;
+    }
+    // select candidate `adv` (static indices only: the arrays stay in registers)
+    double c_bw = bw[0], n_bw = bw[1];
+    int32_t c_ke = ke[0], n_ke = ke[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 1; i <= kCatch; i++) {
+        const bool pick = adv == i;
+        c_bw = pick ? bw[i] : c_bw; n_bw = pick ? bw[i + 1] : n_bw;
+        c_ke = pick ? ke[i] : c_ke; n_ke = pick ? ke[i + 1] : n_ke;
+    }
+    s.j += adv;
+    s.tpos = trace_wrap(s.tpos + adv, s.tlen);
+    st.c = c_bw * kTickDt; st.bw_next = n_bw; st.ke = c_ke; st.ke_next = n_ke;
+    st.tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
+    return st;
+}
+
+// One decision, after lanej_begin_step: download a chunk of target_size, then run to the
+// next call site.  `action` only labels the step (last_action).
+ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepStart &st,
+                                          double target, int32_t action) {
     StepResult r;
     r.bw = 0.0; r.hit = false; r.ended = false; r.timeout = false;
     const int32_t mt = t.max_ticks;
     // ---- phase A: downloaded_size over the trace intervals ----
-    int32_t ke = t.interval_tick[s.j + 1];
-    while (s.k >= ke) {                       // phase B moved k only: catch j/tpos up
-        s.j++;
-        s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-        ke = t.interval_tick[s.j + 1];
-    }
     // One flat loop over chain SEGMENTS (abr_exact_jump.h); a lane moves on to its next
     // trace interval between two segments.  The next interval's bandwidth and end tick
     // are loaded one interval ahead so the loads overlap the arithmetic.
     const int32_t lim = mt - s.k;
-    int32_t tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-    double c = s.trace[s.tpos] * kTickDt;     // bandwidth * dt, the product first  (:160)
-    double bw_next = s.trace[tn];
-    int32_t ke_next = t.interval_tick[s.j + 2];
+    int32_t ke = st.ke, ke_next = st.ke_next, tn = st.tn;
+    double c = st.c, bw_next = st.bw_next;
     ChainState cs;
     cs.x = 0.0; cs.d = 0.0; cs.inb = 0;       // downloaded_size = 0 at a call site
     int32_t n_dl = 0, kk = s.k;
@@ -181,6 +245,7 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
         n_dl += adds; kk += adds;
     }
     const double dl = cs.x;
+    const double g_ndl = t.G[n_dl];           // download_time; loaded now, divided by much later
     // ---- buffer side of the ticks before the completing one ----
     lanej_idle(s, t, hit ? n_dl - 1 : n_dl);
     if (!hit) { r.timeout = true; return r; }
@@ -195,10 +260,10 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
     s.su = s.su && !(b >= t.start_up_length);                                // :201-202
     s.k++;                                                                   // :205
     r.hit = true;
-    r.bw = dl / t.G[n_dl];                                                   // :164
+    r.bw = dl / g_ndl;                                                       // :164
     s.last_action = action;
     s.chunk_id++;                                                            // :166
-    s.avail_k = t.avail_tick[s.chunk_id];
+    s.avail_k = st.avail_next;
     r.ended = s.chunk_id >= t.V;                                             // :207-208
     r.timeout = !r.ended && s.k >= mt;
     if (!r.ended && !r.timeout) {
@@ -207,6 +272,12 @@ ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t a
         r.timeout = !lanej_wait_call(s, t);                                  // phase B
     }
     return r;
+}
+
+// begin + download + wait in one call (host harness)
+ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t action) {
+    const StepStart st = lanej_begin_step(s, t);
+    return lanej_download_and_wait(s, t, st, target, action);
 }
 
 }  // namespace abrx

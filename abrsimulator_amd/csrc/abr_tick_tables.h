@@ -40,12 +40,12 @@ inline TickTables build_tick_tables(double interval, double chunk_length, double
         g += dt;                          // :205 (and :138,:140,:161)
         gp += t.sd;                       // :182-183
     }
-    t.interval_tick.assign((size_t)n_intervals + 2, INT_MAX);
+    t.interval_tick.assign((size_t)n_intervals + 8, INT_MAX);   // slack: look-ahead reads up to j + 6
     {
         int64_t jcur = 0;
-        for (int32_t k = 0; k <= mt && jcur < n_intervals + 2; k++) {
+        for (int32_t k = 0; k <= mt && jcur < n_intervals + 8; k++) {
             int64_t idx = (int64_t)(t.G[k] / interval);                    // :158
-            while (jcur <= idx && jcur < n_intervals + 2) t.interval_tick[jcur++] = k;
+            while (jcur <= idx && jcur < n_intervals + 8) t.interval_tick[jcur++] = k;
         }
     }
     t.min_interval_ticks = INT_MAX;
