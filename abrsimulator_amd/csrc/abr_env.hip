@@ -929,7 +929,11 @@ struct MpcLds {
     int B, heff;
 };
 
-struct Best { double J; int32_t flat; };
+// Running best of one thread: x = -J (so the arg-min of J is the FIRST arg-max of x).
+// idx is the flat index of the winning innermost GROUP (the B leaves that share their first
+// H-1 digits) -- the winning leaf inside it is resolved once per lane at the end -- or, when
+// a clipped horizon ends above the innermost level, of the winning leaf itself.
+struct Best { double x; int32_t idx; };
 
 // Depth-first enumeration with prefix sharing: the partial sums of objective()
 // (mpc.py:144-156) after level i depend only on R[0..i], and are formed in the
@@ -950,7 +954,28 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
                                         double q, double v, double rb, double buf,
                                         double br_prev, int32_t flat, Best &best) {
     const int B = BC ? BC : t.B;
-    if constexpr (BC > 0 && LVL >= H - 2) {
+    if constexpr (LVL == H - 1) {
+        // innermost level: only the group maximum is tracked (v_max_f64 per leaf instead of
+        // compare + three selects); ties inside the group are resolved by mpc_resolve_group
+        double g = -INFINITY;
+        if constexpr (BC > 0) {
+#pragma unroll
+            for (int r = 0; r < BC; r++) {
+                const double b = bl[r];
+                const double x = ((q + b) - t.wv * (v + fabs(b - br_prev))) - t.wr * (rb + (rl[r] - buf));
+                g = fmax(g, x);
+            }
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < B; r++) {
+                const double b = t.brv[LVL * B + r];
+                const double x = ((q + b) - t.wv * (v + fabs(b - br_prev))) -
+                                 t.wr * (rb + (t.rbt[LVL * B + r] - buf));
+                g = fmax(g, x);
+            }
+        }
+        if (g > best.x) { best.x = g; best.idx = flat; }
+    } else if constexpr (BC > 0 && LVL >= H - 2) {
 #pragma unroll
         for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
     } else {
@@ -959,23 +984,21 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
     }
 }
 
+// inner node (LVL < H - 1)
 template <int LVL, int H, int BC>
 __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
                                          int r, double q, double v, double rb, double buf,
                                          double br_prev, int32_t flat, Best &best) {
     const int B = BC ? BC : t.B;
-    constexpr bool kLast = (LVL == H - 1);
-    constexpr bool kRegs = kLast && (BC > 0);
-    const double b = kRegs ? bl[r] : t.brv[LVL * B + r];
-    const double rt = kRegs ? rl[r] : t.rbt[LVL * B + r];
+    const double b = t.brv[LVL * B + r];
     const double q2 = q + b;                                  // :146
     const double v2 = v + fabs(b - br_prev);                  // :148-149
-    const double rb2 = rb + (rt - buf);                       // :151-152
+    const double rb2 = rb + (t.rbt[LVL * B + r] - buf);       // :151-152
     const int32_t f2 = flat * B + r;
-    const bool leaf = kLast || (LVL == t.heff - 1);
-    if (leaf) {
-        const double J = -((q2 - t.wv * v2) - t.wr * rb2);    // :158-162 (startup term is 0)
-        if (J < best.J) { best.J = J; best.flat = f2; }
+    if (LVL == t.heff - 1) {
+        // a clipped horizon (D12) ends here: this node is a leaf
+        const double x = (q2 - t.wv * v2) - t.wr * rb2;       // = -J, :158-162 (startup term is 0)
+        if (x > best.x) { best.x = x; best.idx = f2; }
     } else {
         if constexpr (LVL + 1 < H) {
             const double tmp = pymax0(buf - t.tdl[LVL * B + r]);               // :107,:116
@@ -986,6 +1009,35 @@ __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, cons
             mpc_dfs<LVL + 1, H, BC>(t, bl, rl, q2, v2, rb2, nb, bp, f2, best);
         }
     }
+}
+
+// The first leaf of innermost group `gflat` whose x equals the group maximum `xbest`:
+// re-walks the H-1 fixed digits with the same operation sequence as the search, then
+// scans the B leaves in order.  Runs once per lane.
+__device__ inline int32_t mpc_resolve_group(const MpcLds &t, int H, int32_t gflat, int prev0,
+                                            double buf, double xbest) {
+    const int B = t.B;
+    int32_t pw = 1;
+    for (int i = 0; i < H - 2; i++) pw *= B;
+    double q = 0.0, v = 0.0, rb = 0.0;
+    double bp = t.brv[prev0];
+    for (int lvl = 0; lvl < H - 1; lvl++) {
+        const int r = (gflat / pw) % B;
+        pw = (pw >= B) ? pw / B : 1;
+        const double b = t.brv[lvl * B + r];
+        q = q + b; v = v + fabs(b - bp); rb = rb + (t.rbt[lvl * B + r] - buf);
+        const double tmp = pymax0(buf - t.tdl[lvl * B + r]);
+        const double wait = pymax0(tmp + t.L - t.max_buffer);
+        buf = pymax0(tmp + t.L - wait);
+        bp = t.brv[(lvl + 1) * B + r];
+    }
+    const int lvl = H - 1;
+    for (int r = 0; r < B; r++) {
+        const double b = t.brv[lvl * B + r];
+        const double x = ((q + b) - t.wv * (v + fabs(b - bp))) - t.wr * (rb + (t.rbt[lvl * B + r] - buf));
+        if (x == xbest) return gflat * B + r;
+    }
+    return gflat * B;     // unreachable: xbest was produced by this very arithmetic
 }
 
 constexpr int kMpcLanesPerBlock = 16;
@@ -1050,7 +1102,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     }
     __syncthreads();
     // ---- phase 3: each thread walks its prefix, then enumerates its subtree ----
-    Best best; best.J = INFINITY; best.flat = 0x7fffffff;
+    Best best; best.x = -INFINITY; best.idx = 0x7fffffff;
     if (valid && heff_s[li] > 0) {
         MpcLds t;
         t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
@@ -1089,7 +1141,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
                 for (int r = 0; r < BC; r++) { bl[r] = t.brv[(H - 1) * B + r]; rl[r] = t.rbt[(H - 1) * B + r]; }
             }
             if (is_leaf) {
-                best.J = -((q - t.wv * v) - t.wr * rb); best.flat = flat;
+                best.x = (q - t.wv * v) - t.wr * rb; best.idx = flat;
             } else if (D == 2) {
                 if constexpr (H >= 3)
                     mpc_dfs<2, H, BC>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
@@ -1099,27 +1151,34 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             }
         }
     }
-    if (li < LPB) { bestJ[li * T + pre] = best.J; bestF[li * T + pre] = best.flat; }
+    if (li < LPB) { bestJ[li * T + pre] = best.x; bestF[li * T + pre] = best.idx; }
     __syncthreads();
-    // ---- phase 4: arg-min over the T prefixes of a lane (ascending prefix = ascending flat) ----
+    // ---- phase 4: first arg-max of x = -J over the T prefixes of a lane (ascending prefix =
+    //      ascending flat index), then the winning leaf inside the winning group ----
     if (valid && pre == 0) {
-        double bj = INFINITY; int32_t bf = 0x7fffffff; bool have = false;
+        double bx = -INFINITY; int32_t bf = 0x7fffffff; bool have = false;
         for (int q2 = 0; q2 < T; q2++) {
-            const double J = bestJ[li * T + q2];
+            const double x = bestJ[li * T + q2];
             const int32_t f = bestF[li * T + q2];
             if (f == 0x7fffffff) continue;
-            if (!have || J < bj) { bj = J; bf = f; have = true; }
+            if (!have || x > bx) { bx = x; bf = f; have = true; }
         }
         const int he = heff_s[li];
         int32_t act = -1;
         if (have) {
+            if (he == H) {
+                MpcLds t;
+                t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
+                t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = he;
+                bf = mpc_resolve_group(t, H, bf, p.prev[lane], p.buffer[lane], bx);
+            }
             int32_t lead = 1;
             for (int i = 1; i < he; i++) lead *= B;
             act = bf / lead;                                   // int(result[0])  mpc.py:186
         }
         p.action_out[lane] = act;
         if (p.flat_out) p.flat_out[lane] = have ? bf : -1;
-        if (p.J_out) p.J_out[lane] = have ? bj : NAN;
+        if (p.J_out) p.J_out[lane] = have ? -bx : NAN;
     }
 }
 
