@@ -162,11 +162,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+    # rehearsal knobs (a 1-GPU box cannot run RCCL with 2 ranks): ABR_BENCH_ONE_DEVICE=1 puts every
+    # rank on cuda:0, ABR_BENCH_BACKEND=gloo swaps the backend.  The driver's runs use neither.
+    if os.environ.get("ABR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ABR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import abrsimulator_amd as A
     from abrsimulator_amd._lib import OBS_DIM
