@@ -23,6 +23,10 @@ def pack_traces(traces: Sequence, device):
     off = torch.zeros(len(ts), dtype=torch.int64)
     off[1:] = torch.cumsum(lens[:-1].to(torch.int64), 0)
     flat = torch.cat(ts)
+    # a NaN/inf/negative bandwidth can never complete a download: the lane would crawl to
+    # max_ticks one real addition at a time (bounded, but pointlessly slow)
+    if not bool(torch.isfinite(flat).all()) or bool((flat < 0).any()):
+        raise ValueError("bandwidth traces must be finite and non-negative")
     return flat.to(device), off.to(device), lens.to(device)
 
 

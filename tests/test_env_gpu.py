@@ -216,8 +216,9 @@ def test_bad_action_and_masked_reset_and_checkpoint():
     assert torch.equal(before[keep.cuda()], after[keep.cuda()])
 
 
-def test_full_size_properties():
-    """BASELINE.json size (65 536 lanes): properties that need no oracle run."""
+def test_full_size_properties(oracle):
+    """BASELINE.json size (65 536 lanes): size-independent properties on every lane, and an
+    exact oracle replay of 2 048 lanes sampled across the whole index range."""
     N, V = 65536, 48
     rng = np.random.default_rng(0)
     traces = [rng.uniform(0.2, 6.0, 1000).astype(np.float32).astype(np.float64) for _ in range(1024)]
@@ -248,6 +249,20 @@ def test_full_size_properties():
     q = env.episode_qoe()
     lat = env.observe_f64()["average_latency"]
     assert torch.allclose(out["reward"].double().sum(0) + 0.1 * lat, q, rtol=2e-5, atol=1e-3)
+    # exact replay of a sample of lanes (first, last, and random ones in between)
+    pick = np.unique(np.concatenate([[0, 1, 63, 64, N - 1, N - 64], rng.integers(0, N, 2048)]))
+    acts = out2["actions"].cpu().numpy()[:, pick].T.copy()
+    cfg = oracle.env_cfg(meta["ladder"], 4.0, V, 20.0, 8.0, 1.0, meta["weights"], 1.0)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid.numpy()[pick], off.numpy()[pick], acts)
+    o = obs.cpu().numpy()[:, :, pick]               # o[s] = observation after step s
+    for s in range(V - 1):
+        assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32))
+        assert np.array_equal(o[s, 4], steps["global_time"][:, s + 1].astype(np.float32))
+        assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32))
+        assert np.array_equal(o[s, 6], steps["rebuffer_time"][:, s + 1].astype(np.float32))
+    ah, bh = env.history()
+    assert np.array_equal(bh.cpu().numpy()[:, pick].T, bw)          # float64 throughputs, bit-exact
+    assert np.allclose(q.cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
 
 
 def test_simulator_class_runs_reference_style_script(tmp_path):

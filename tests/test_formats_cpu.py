@@ -35,3 +35,13 @@ def test_mpd_file(tmp_path):
     open(p, "a").write("1 2\n")
     with pytest.raises(ValueError):
         A.load_mpd_file(4, 20, 8, p)
+
+
+def test_pack_traces_rejects_bad_bandwidths():
+    import torch
+    from abrsimulator_amd.env import pack_traces
+    flat, off, lens = pack_traces([[1.0, 2.0], [3.0]], "cpu")
+    assert flat.tolist() == [1.0, 2.0, 3.0] and off.tolist() == [0, 2] and lens.tolist() == [2, 1]
+    for bad in ([[1.0, float("nan")]], [[float("inf")]], [[-0.5, 1.0]], [[]], []):
+        with pytest.raises(ValueError):
+            pack_traces(bad, "cpu")
