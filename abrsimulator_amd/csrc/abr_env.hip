@@ -80,6 +80,8 @@ struct EnvParams {
     const int32_t *trace_len;
     // per-lane state, SoA (device, in the workspace)
     double *buf, *last_bw, *hist_n, *hist_s;
+    double *sd_lane, *pt_lane;     // per-lane speed*dt and play_time (only touched when lane_speeds != nullptr)
+    const double *lane_speeds;     // caller-owned per-lane play speeds, or nullptr: one speed for all lanes
     long long *sumk;               // sum of tick indices of playing ticks (latency integral)
     int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *j, *tpos, *trace_id, *offset0;
     int32_t *last_action, *n_su_obs, *n_rb_obs, *episode_no;
@@ -198,10 +200,13 @@ __device__ inline void lane_refresh_interval(Lane &s, const EnvParams &p) {
 //   sum = sum_m (G[k_m] - GP[m])  ~=  dt * sum_m k_m - sd * n_play (n_play - 1) / 2
 // which differs from the reference only by float64 drift of the clocks
 // (<= 1e-11 relative, measured in tests); it feeds no decision.
-__device__ inline double lane_avg_latency(const EnvParams &p, long long sumk, int32_t n_play) {
+__device__ inline double avg_latency_from(double sd, double play_time, long long sumk, int32_t n_play) {
     if (n_play == 0) return 0.0;
     double tri = (double)(((long long)n_play * (n_play - 1)) / 2);
-    return (kDt * (double)sumk - p.sd * tri) / p.GP[n_play];
+    return (kDt * (double)sumk - sd * tri) / play_time;
+}
+__device__ inline double lane_avg_latency(const EnvParams &p, long long sumk, int32_t n_play) {
+    return avg_latency_from(p.sd, p.GP[n_play], sumk, n_play);
 }
 
 __device__ inline void lane_load(Lane &s, const EnvParams &p, int64_t i) {
@@ -463,6 +468,7 @@ __device__ inline abrx::Tables make_tables(const EnvParams &p) {
     t.G = p.G; t.interval_tick = p.interval_tick; t.avail_tick = p.avail_tick;
     t.L = p.chunk_length; t.sd = p.sd; t.max_buffer = p.max_buffer;
     t.start_up_length = p.start_up_length; t.V = p.video_length; t.max_ticks = p.max_ticks;
+    t.per_lane_speed = p.lane_speeds != nullptr;
     return t;
 }
 
@@ -475,6 +481,7 @@ __device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
     s.su = f & kFlagStartUp; s.be = f & kFlagBufEmpty; s.bf = f & kFlagBufFull;
     const int32_t c = s.chunk_id < p.video_length ? s.chunk_id : p.video_length;
     s.avail_k = p.avail_tick[c];
+    if (p.lane_speeds) { s.sd = p.sd_lane[i]; s.pt = p.pt_lane[i]; } else { s.sd = p.sd; s.pt = 0.0; }
 }
 
 __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i) {
@@ -483,6 +490,7 @@ __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i
     p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
                            (s.bf ? kFlagBufFull : 0));
+    if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
 }
 
 __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i, float *obs,
@@ -494,7 +502,7 @@ __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i
     obs[ABR_OBS_LAST_BANDWIDTH * n + i] = (float)last_bw;
     obs[ABR_OBS_BUFFER_LEVEL * n + i] = (float)s.buf;
     obs[ABR_OBS_GLOBAL_TIME * n + i] = (float)p.G[s.k];
-    obs[ABR_OBS_PLAY_TIME * n + i] = (float)p.GP[s.n_play];
+    obs[ABR_OBS_PLAY_TIME * n + i] = (float)(p.lane_speeds ? s.pt : p.GP[s.n_play]);
     obs[ABR_OBS_REBUFFER_TIME * n + i] = (float)p.G[s.n_rb];
     obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
 }
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                 offset0 = offset_in ? offset_in[i] : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+                s.sd = p.lane_speeds ? p.lane_speeds[i] * kDt : p.sd;     // play_speed * dt (:182)
                 abrx::lanej_init(s, tb, offset0);
                 if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                 write_obs_j(s, p, i, obs_out, 0.0);
@@ -590,7 +599,9 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                     if (r.ended || r.timeout) {
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
-                        p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
+                        p.ep_qoe_terms[2 * p.n_lanes + i] =
+                            p.lane_speeds ? avg_latency_from(s.sd, s.pt, s.sumk, s.n_play)
+                                          : lane_avg_latency(p, s.sumk, s.n_play);
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
                             for (int c = 0; c < V; c++)
@@ -647,14 +658,30 @@ __global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
     out[ABR_F64_GLOBAL_TIME * n + i] = p.G[p.k[i]];
     out[ABR_F64_REBUFFER_TIME * n + i] = p.G[p.n_rb[i]];
     out[ABR_F64_STARTUP_TIME * n + i] = p.G[p.n_su[i]];
-    out[ABR_F64_PLAY_TIME * n + i] = p.GP[p.n_play[i]];
-    out[ABR_F64_AVERAGE_LATENCY * n + i] = lane_avg_latency(p, p.sumk[i], p.n_play[i]);
+    int32_t P = p.play_ticks_per_chunk;
+    if (p.lane_speeds) {
+        // per-lane speed: ticks per played chunk = additions of speed*dt from 0 until >= L (:185)
+        double x = 0.0; int32_t a = 0;
+        abrx::chain<abrx::STOP_GE>(x, p.sd_lane[i], p.chunk_length, p.max_ticks + 1, a);
+        P = a > 0 ? a : 1;
+        out[ABR_F64_PLAY_TIME * n + i] = p.pt_lane[i];
+        out[ABR_F64_AVERAGE_LATENCY * n + i] = avg_latency_from(p.sd_lane[i], p.pt_lane[i], p.sumk[i], p.n_play[i]);
+    } else {
+        out[ABR_F64_PLAY_TIME * n + i] = p.GP[p.n_play[i]];
+        out[ABR_F64_AVERAGE_LATENCY * n + i] = lane_avg_latency(p, p.sumk[i], p.n_play[i]);
+    }
     out[ABR_F64_BUFFER_LEVEL * n + i] = p.buf[i];
     // play_length restarts from 0 every P playing ticks (:185-187); play_id counts the restarts
-    out[ABR_F64_PLAY_LENGTH * n + i] = p.GP[p.n_play[i] % p.play_ticks_per_chunk];
+    if (p.lane_speeds) {
+        double x = 0.0; int32_t a = 0;
+        abrx::chain<abrx::STOP_GE>(x, p.sd_lane[i], 1.0e300, p.n_play[i] % P, a);
+        out[ABR_F64_PLAY_LENGTH * n + i] = x;
+    } else {
+        out[ABR_F64_PLAY_LENGTH * n + i] = p.GP[p.n_play[i] % P];
+    }
     out[ABR_F64_LAST_BANDWIDTH * n + i] = p.last_bw[i];
     out[ABR_F64_CHUNK_ID * n + i] = (double)p.chunk_id[i];
-    out[ABR_F64_PLAY_ID * n + i] = (double)(p.n_play[i] / p.play_ticks_per_chunk);
+    out[ABR_F64_PLAY_ID * n + i] = (double)(p.n_play[i] / P);
     out[ABR_F64_LAST_BITRATE * n + i] = (double)p.last_action[i];
     out[ABR_F64_FLAGS * n + i] = (double)p.flags[i];
     out[ABR_F64_HIST_N * n + i] = p.hist_n[i];
@@ -717,7 +744,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->GP = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
     L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 8), A);
     L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
-    L->f64_state = o; o = align_up(o + sizeof(double) * 4 * N, A);
+    L->f64_state = o; o = align_up(o + sizeof(double) * 6 * N, A);
     L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);
     L->i32_state = o; o = align_up(o + sizeof(int32_t) * 13 * N, A);
     L->u8_state = o; o = align_up(o + 2 * N, A);
@@ -790,6 +817,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     const size_t N = (size_t)n_lanes;
     double *f = (double *)(w + L.f64_state);
     p.buf = f; p.last_bw = f + N; p.hist_n = f + 2 * N; p.hist_s = f + 3 * N;
+    p.sd_lane = f + 4 * N; p.pt_lane = f + 5 * N; p.lane_speeds = nullptr;
     p.sumk = (long long *)(w + L.i64_state);
     int32_t *q = (int32_t *)(w + L.i32_state);
     p.k = q; p.chunk_id = q + N; p.n_su = q + 2 * N; p.n_rb = q + 3 * N; p.n_play = q + 4 * N;
@@ -828,7 +856,18 @@ extern "C" int abr_env_destroy(abr_env *env) {
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (impl != 0 && impl != 1) return fail(ABR_E_INVALID, "impl must be 0 (jump) or 1 (tick)");
+    if (impl == 1 && env->p.lane_speeds)
+        return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
+    return ABR_OK;
+}
+
+// one constant play speed per lane (8f rank 3); nullptr restores the single config speed
+extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (speeds_dev && env->impl)
+        return fail(ABR_E_UNSUPPORTED, "per-lane speeds need the event-driven kernels (impl 0)");
+    env->p.lane_speeds = speeds_dev;
     return ABR_OK;
 }
 

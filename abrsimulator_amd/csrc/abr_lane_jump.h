@@ -41,10 +41,13 @@ struct Tables {
     const int32_t *avail_tick;     // first tick k with int(G[k]/chunk_length) - 1 >= c  (:143)
     double L, sd, max_buffer, start_up_length;
     int32_t V, max_ticks;
+    bool per_lane_speed;           // each lane carries its own speed*dt and play_time (8f rank 3)
 };
 
 struct LaneJ {
     double buf;                    // buffer_level
+    double sd;                     // this lane's speed*dt (== Tables::sd unless per_lane_speed)
+    double pt;                     // play_time, carried only when per_lane_speed (else GP[n_play])
     long long sumk;                // sum of tick indices of playing ticks (latency integral)
     int32_t k, chunk_id, n_su, n_rb, n_play, j, tpos, tlen, avail_k, last_action;
     bool su, be, bf;               // start_up, buffer_empty, buffer_full
@@ -59,6 +62,19 @@ ABR_HD void lanej_init(LaneJ &s, const Tables &t, int32_t offset0) {
     s.su = true; s.be = true; s.bf = false;
     s.j = 0; s.tpos = offset0 % s.tlen;
     s.avail_k = t.avail_tick[0];
+    s.pt = 0.0;                    // play_time = 0 (:115); s.sd is set by the caller
+}
+
+// play_time += speed*dt for `a` playing ticks (:182).  With one speed for all lanes
+// play_time is the table value GP[n_play]; with per-lane speeds it is carried, advanced by
+// the same exact chain machinery.
+ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
+    if (!t.per_lane_speed || a <= 0) return;
+    int32_t done = 0;
+    double x = s.pt;
+    // an unreachable threshold: the chain only counts
+    chain<STOP_GE>(x, s.sd, 1.0e300, a, done);
+    s.pt = x;
 }
 
 // m full iterations: T4-T9 of a tick in which no chunk completes, then T1-T3 of the next
@@ -71,7 +87,8 @@ ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     } else {
         int32_t a = 0;
         double b = s.buf;
-        const bool zero = chain<STOP_LE>(b, -t.sd, 0.0, m, a);                 // :184,:194
+        const bool zero = chain<STOP_LE>(b, -s.sd, 0.0, m, a);                 // :184,:194
+        lanej_play(s, t, a);
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
         if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
@@ -101,7 +118,8 @@ ABR_HD bool lanej_wait_call(LaneJ &s, const Tables &t) {
         }
         int32_t a = 0;
         double b = s.buf;
-        const bool cleared = chain<STOP_LT>(b, -t.sd, t.max_buffer, mt - s.k, a);
+        const bool cleared = chain<STOP_LT>(b, -s.sd, t.max_buffer, mt - s.k, a);
+        lanej_play(s, t, a);
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
         s.k += a;
@@ -252,7 +270,7 @@ ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepS
     // ---- the completing tick (:163-170, then :174-202) ----
     const bool playing = !(s.be || s.su);
     double b = s.buf + t.L;                                                  // :170
-    if (playing) { s.sumk += s.k; s.n_play++; b = b - t.sd; }                // :184
+    if (playing) { s.sumk += s.k; s.n_play++; b = b - s.sd; lanej_play(s, t, 1); }   // :182-184
     s.bf = b >= t.max_buffer;                                                // :190
     s.be = b <= 0.0;                                                         // :194
     if (s.be) b = 0.0;

@@ -42,7 +42,7 @@ class BatchedABREnv:
     """
 
     def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
-                 device="cuda", speed: float = 1.0, auto_reset: bool = False, max_ticks: int = 0,
+                 device="cuda", speed=1.0, auto_reset: bool = False, max_ticks: int = 0,
                  lane_id_base: int = 0, impl: str = "jump"):
         self.lib = _lib.lib()
         self.device = torch.device(device)
@@ -59,6 +59,14 @@ class BatchedABREnv:
         cfg.variance_weight = float(qoe_metric.variance_weight)
         cfg.startup_weight = float(qoe_metric.startup_weight)
         cfg.latency_weight = float(getattr(qoe_metric, "latency_weight", 0.0))
+        self.lane_speeds = None
+        if torch.is_tensor(speed) or hasattr(speed, "__len__"):
+            # one constant play speed per lane
+            ls = torch.as_tensor(speed, dtype=torch.float64).reshape(-1)
+            if ls.numel() != self.n_lanes or not bool((ls > 0).all()) or not bool(torch.isfinite(ls).all()):
+                raise ValueError("per-lane speeds must be n_lanes finite values > 0")
+            self.lane_speeds = ls.to(self.device).contiguous()
+            speed = 1.0
         cfg.speed = float(speed)
         if len(ladder) > _lib.MAX_RATES:
             raise ValueError(f"at most {_lib.MAX_RATES} bitrates")
@@ -92,6 +100,8 @@ class BatchedABREnv:
             raise ValueError("impl must be 'jump' (event-driven kernels) or 'tick'")
         self.impl = impl
         _lib.check(self.lib.abr_env_set_impl(self._h, 1 if impl == "tick" else 0))
+        if self.lane_speeds is not None:
+            _lib.check(self.lib.abr_env_set_lane_speeds(self._h, _lib.ptr(self.lane_speeds)))
         self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(self.n_lanes, dtype=torch.float32, device=self.device)
         self.done = torch.zeros(self.n_lanes, dtype=torch.uint8, device=self.device)

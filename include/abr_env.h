@@ -124,6 +124,12 @@ int abr_env_destroy(abr_env *env);
  * reproduces the unsharded one.  Default 0. */
 int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
 
+/* One constant play speed per lane instead of config.speed (what a per-lane speed
+ * controller that always answers the same value would do, Simulator.py:176-177).
+ * speeds_dev: float64 [n_lanes], > 0, must stay valid until the next abr_env_reset has run;
+ * takes effect at that reset.  NULL restores the single speed.  Event-driven kernels only. */
+int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);
+
 /* Which kernels serve reset/step: 0 (default) = event-driven, exact closed-form
  * stepping of the float64 tick sequences; 1 = one loop trip per 0.01 s tick.  Both
  * produce identical state; 1 exists as an independent cross-check. */

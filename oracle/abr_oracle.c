@@ -209,6 +209,33 @@ int64_t oracle_env_batch(const oracle_env_cfg *c, const double *traces, const in
     return total;
 }
 
+/* Same, with one constant play speed per lane (what a per-lane speed controller that
+ * always answers the same value would do, Simulator.py:176-177).  speeds[n_lanes]. */
+int64_t oracle_env_batch_speeds(const oracle_env_cfg *c, const double *traces,
+                                const int64_t *trace_off, const int32_t *trace_len,
+                                const int32_t *trace_id, const int32_t *offset,
+                                const int32_t *actions, const double *speeds, int32_t n_lanes,
+                                oracle_step_rec *steps, double *bw_out, oracle_final_rec *fin,
+                                int64_t max_ticks)
+{
+    const int V = c->video_length;
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_lanes; i++) {
+        oracle_env_cfg ci = *c;
+        ci.speed = speeds[i];
+        oracle_final_rec f;
+        int t = trace_id[i];
+        int rc = oracle_env_episode(&ci, traces + trace_off[t], trace_len[t], offset[i],
+                                    actions + (size_t)i * V, NULL, NULL,
+                                    steps ? steps + (size_t)i * V : NULL,
+                                    bw_out ? bw_out + (size_t)i * V : NULL, NULL, &f, max_ticks);
+        if (rc) return rc;
+        if (fin) fin[i] = f;
+        total += f.ticks;
+    }
+    return total;
+}
+
 /* ------------------------------------------------------------------------
  * MPC (mpc.py)
  * ---------------------------------------------------------------------- */

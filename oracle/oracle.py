@@ -57,6 +57,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.oracle_env_batch.restype = C.c_int64
+        _LIB.oracle_env_batch_speeds.restype = C.c_int64
         _LIB.oracle_mpc_brute.restype = C.c_int64
         _LIB.oracle_mpc_objective.restype = C.c_double
         assert STEP_DTYPE.itemsize == 96 and FINAL_DTYPE.itemsize == 72
@@ -89,8 +90,9 @@ def pack_traces(traces):
     return np.ascontiguousarray(flat), off, lens
 
 
-def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40):
-    """Replay episodes. traces: list of arrays. actions: [N, V] int32.
+def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=None):
+    """Replay episodes. traces: list of arrays. actions: [N, V] int32.  speeds: optional
+    per-lane constant play speeds [N] (default: cfg.speed for every lane).
     Returns (steps[N,V] STEP_DTYPE, bw[N,V], final[N] FINAL_DTYPE, total_ticks)."""
     flat, off, lens = pack_traces(traces)
     trace_id = np.ascontiguousarray(trace_id, np.int32)
@@ -101,11 +103,20 @@ def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40):
     steps = np.zeros((N, V), STEP_DTYPE)
     bw = np.zeros((N, V), np.float64)
     fin = np.zeros(N, FINAL_DTYPE)
-    rc = lib().oracle_env_batch(
-        C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
-        _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32), C.c_int32(N),
-        steps.ctypes.data_as(C.c_void_p), _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p),
-        C.c_int64(max_ticks))
+    if speeds is not None:
+        speeds = np.ascontiguousarray(speeds, np.float64)
+        assert speeds.shape == (N,)
+        rc = lib().oracle_env_batch_speeds(
+            C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
+            _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32),
+            _p(speeds, C.c_double), C.c_int32(N), steps.ctypes.data_as(C.c_void_p),
+            _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p), C.c_int64(max_ticks))
+    else:
+        rc = lib().oracle_env_batch(
+            C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
+            _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32), C.c_int32(N),
+            steps.ctypes.data_as(C.c_void_p), _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p),
+            C.c_int64(max_ticks))
     if rc < 0:
         raise RuntimeError(f"oracle_env_batch failed: {rc}")
     return steps, bw, fin, int(rc)

@@ -24,7 +24,7 @@ void *lj_create(double interval, double L, double speed, int32_t V, double max_b
     c->t.interval_tick = c->tt.interval_tick.data();
     c->t.avail_tick = c->tt.avail_tick.data();
     c->t.L = L; c->t.sd = c->tt.sd; c->t.max_buffer = max_buffer; c->t.start_up_length = start_up_length;
-    c->t.V = V; c->t.max_ticks = max_ticks;
+    c->t.V = V; c->t.max_ticks = max_ticks; c->t.per_lane_speed = false;
     c->n_rates = n_rates;
     for (int i = 0; i < n_rates; i++) c->ladder[i] = ladder[i];
     return c;
@@ -37,17 +37,20 @@ void lj_destroy(void *h) { delete (Ctx *)h; }
 // fin[0..5] = global_time, rebuffer_time, start_up_time, play_time, buffer_level, sumk; fin_i[0]=n_play
 // returns 0, or -2 on timeout
 int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const int32_t *actions,
-               double *rec, double *bw_out, double *fin, int32_t *fin_i) {
+               double *rec, double *bw_out, double *fin, int32_t *fin_i, double lane_speed) {
     Ctx *c = (Ctx *)h;
-    const abrx::Tables &t = c->t;
+    abrx::Tables t = c->t;
     abrx::LaneJ s;
     s.trace = trace; s.tlen = tlen;
+    s.sd = t.sd;
+    if (lane_speed > 0.0) { t.per_lane_speed = true; s.sd = lane_speed * 0.01; }   // :182 product
     abrx::lanej_init(s, t, offset);
     if (!abrx::lanej_wait_call(s, t)) return -2;
     double last_bw = 0.0;
     for (int step = 0; step < t.V; step++) {
         double *r = rec + (size_t)step * 8;
-        r[0] = t.G[s.k]; r[1] = t.G[s.n_rb]; r[2] = t.G[s.n_su]; r[3] = c->tt.GP[s.n_play];
+        r[0] = t.G[s.k]; r[1] = t.G[s.n_rb]; r[2] = t.G[s.n_su];
+        r[3] = t.per_lane_speed ? s.pt : c->tt.GP[s.n_play];
         r[4] = s.buf; r[5] = last_bw; r[6] = (double)s.sumk;
         r[7] = (double)((s.su ? 1 : 0) | (s.be ? 2 : 0) | (s.bf ? 4 : 0));
         int a = actions[step];
@@ -57,7 +60,8 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
         bw_out[step] = sr.bw;
         if (sr.ended != (step == t.V - 1)) return -5;
     }
-    fin[0] = t.G[s.k]; fin[1] = t.G[s.n_rb]; fin[2] = t.G[s.n_su]; fin[3] = c->tt.GP[s.n_play];
+    fin[0] = t.G[s.k]; fin[1] = t.G[s.n_rb]; fin[2] = t.G[s.n_su];
+    fin[3] = t.per_lane_speed ? s.pt : c->tt.GP[s.n_play];
     fin[4] = s.buf; fin[5] = (double)s.sumk;
     fin_i[0] = s.n_play;
     return 0;
@@ -65,14 +69,16 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
 
 int64_t lj_batch(void *h, const double *traces, const int64_t *trace_off, const int32_t *trace_len,
                  const int32_t *trace_id, const int32_t *offset, const int32_t *actions,
-                 int32_t n_lanes, double *rec, double *bw_out, double *fin, int32_t *fin_i) {
+                 int32_t n_lanes, double *rec, double *bw_out, double *fin, int32_t *fin_i,
+                 const double *speeds /* nullable: per-lane play speeds */) {
     Ctx *c = (Ctx *)h;
     const int V = c->t.V;
     for (int32_t i = 0; i < n_lanes; i++) {
         int tid = trace_id[i];
         int rc = lj_episode(h, traces + trace_off[tid], trace_len[tid], offset[i],
                             actions + (size_t)i * V, rec + (size_t)i * V * 8,
-                            bw_out + (size_t)i * V, fin + (size_t)i * 6, fin_i + i);
+                            bw_out + (size_t)i * V, fin + (size_t)i * 6, fin_i + i,
+                            speeds ? speeds[i] : 0.0);
         if (rc) return -(1000 + (int64_t)i * 10 - rc);
     }
     return 0;

@@ -302,3 +302,33 @@ def test_simulator_class_runs_reference_style_script(tmp_path):
         assert np.array_equal(buf.cpu().numpy(), g["buffer_level"][:, c])
         if c:
             assert np.array_equal(bws.cpu().numpy().T, g["final_bandwidths"][:, :c])
+
+
+def test_per_lane_speeds(oracle):
+    """8f rank 3: one constant play speed per lane.  play_time (carried by the exact chain),
+    buffer_level, the clocks, play_id/play_length and the episode QoE against the oracle run
+    with the same per-lane speeds."""
+    meta, traces, trace_id, offset, actions = _random_case(seed=41, N=700, V=10, bw=(0.5, 7.0))
+    N, V = actions.shape
+    speeds = np.random.default_rng(41).choice([0.75, 0.8, 1.0, 1.1, 1.25, 1.3, 0.9173], N)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, speeds=speeds)
+    env = make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N)
+    obs = env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    acts = torch.from_numpy(actions).cuda()
+    for s in range(V):
+        f = env.observe_f64()
+        for k in F64_EXACT:
+            assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (s, k)
+        assert np.array_equal(f["play_id"].cpu().numpy().astype(np.int32), steps["play_id"][:, s])
+        assert np.allclose(f["average_latency"].cpu().numpy(), steps["average_latency"][:, s],
+                           rtol=LAT_RTOL, atol=1e-12)
+        assert np.array_equal(obs.cpu().numpy()[5], steps["play_time"][:, s].astype(np.float32))
+        obs, _, _ = env.step(acts[:, s].contiguous())
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    assert np.array_equal(env.observe_f64()["play_time"].cpu().numpy(), fin["play_time"])
+    # the tick-by-tick kernels take one speed only
+    import abrsimulator_amd as A
+    with pytest.raises(A._lib.AbrError):
+        make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N, impl="tick")

@@ -28,7 +28,7 @@ def H():
     return lib
 
 
-def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0):
+def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0, speeds=None):
     from oracle.oracle import pack_traces
     ladder = np.asarray(meta["ladder"], np.float64)
     V = meta["video_length"]
@@ -46,7 +46,8 @@ def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0):
     P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     rc = H.lj_batch(C.c_void_p(h), P(flat, C.c_double), P(off, C.c_int64), P(lens, C.c_int32),
                     P(trace_id, C.c_int32), P(offset, C.c_int32), P(actions, C.c_int32), C.c_int32(N),
-                    P(rec, C.c_double), P(bw, C.c_double), P(fin, C.c_double), P(fin_i, C.c_int32))
+                    P(rec, C.c_double), P(bw, C.c_double), P(fin, C.c_double), P(fin_i, C.c_int32),
+                    P(np.ascontiguousarray(speeds, np.float64), C.c_double) if speeds is not None else None)
     H.lj_destroy(C.c_void_p(h))
     assert rc == 0, rc
     return rec, bw, fin, fin_i
@@ -119,4 +120,17 @@ def test_seeded_against_oracle(H, oracle, case):
                          meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
     steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions)
     rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions)
+    _check(rec, bw, fin, steps, bwo, fino)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_per_lane_speeds_against_oracle(H, oracle, seed):
+    """8f rank 3: one constant play speed per lane; play_time is then carried by the exact
+    chain instead of the shared GP table."""
+    meta, traces, trace_id, offset, actions = _case(seed=seed, N=1500, V=14, bw=(0.5, 7.0))
+    speeds = np.random.default_rng(seed).choice([0.75, 0.8, 1.0, 1.1, 1.25, 1.3, 0.9173], len(trace_id))
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, speeds=speeds)
+    rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions, speeds=speeds)
     _check(rec, bw, fin, steps, bwo, fino)
