@@ -80,6 +80,10 @@ ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
 // m full iterations: T4-T9 of a tick in which no chunk completes, then T1-T3 of the next
 ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     if (m <= 0) return;
+    // :201-202 at the end of the first of these ticks.  A no-op everywhere (start_up implies
+    // buffer_level < start_up_length once any tick has run) except right after init when
+    // start_up_length <= 0: tick 0 itself counts as start-up, every later one does not.
+    if (s.su && s.buf >= t.start_up_length) s.su = false;
     if (s.su) {
         s.n_su += m;                                   // :137-138; nothing plays, buffer untouched
     } else if (s.be) {

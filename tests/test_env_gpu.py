@@ -332,3 +332,35 @@ def test_per_lane_speeds(oracle):
     import abrsimulator_amd as A
     with pytest.raises(A._lib.AbrError):
         make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N, impl="tick")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_against_oracle(oracle, seed):
+    """Config-space fuzz on the device (the CPU twin of this test runs 60 seeds through the
+    host build of the same lane logic): chunk lengths, trace intervals shorter than the
+    prologue / longer than a chunk / non-representable, ladders of 2-8 rates, buffer limits,
+    start_up_length 0, speeds, ragged traces with wrap-around."""
+    from test_lane_jump_cpu import _random_config
+    rng = np.random.default_rng(1000 + seed)
+    meta, (lo, hi) = _random_config(rng)
+    n_traces, N = 6, 200
+    lens = rng.integers(40, 3000, n_traces)
+    traces = [rng.uniform(lo, hi, l).astype(np.float32).astype(np.float64) for l in lens]
+    trace_id = rng.integers(0, n_traces, N).astype(np.int32)
+    offset = np.array([rng.integers(0, lens[t]) for t in trace_id], np.int32)
+    V = meta["video_length"]
+    actions = rng.integers(0, len(meta["ladder"]), (N, V)).astype(np.int32)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, max_ticks=4_000_000)
+    for impl in IMPLS:
+        env = make_env(meta, traces, N, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
+        env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+        acts = torch.from_numpy(actions).cuda()
+        for s in range(V):
+            f = env.observe_f64()
+            for k in F64_EXACT:
+                assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (impl, s, k)
+            env.step(acts[:, s].contiguous())
+        assert np.array_equal(env.history()[1].cpu().numpy().T, bw), impl
+        assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10), impl

@@ -134,3 +134,43 @@ def test_per_lane_speeds_against_oracle(H, oracle, seed):
     steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, speeds=speeds)
     rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions, speeds=speeds)
     _check(rec, bw, fin, steps, bwo, fino)
+
+
+def _random_config(rng):
+    """A random but playable configuration (the reference loops forever when
+    max_buffer < start_up_length, so keep start_up_length <= max_buffer)."""
+    L = float(rng.choice([1.0, 2.0, 2.5, 3.0, 4.0, 6.0]))
+    interval = float(rng.choice([0.05, 0.25, 0.3, 0.5, 0.7, 1.0, 2.0, 3.7]))
+    B = int(rng.integers(2, 9))
+    ladder = np.sort(rng.uniform(0.2, 8.0, B)).round(3).tolist()
+    max_buffer = float(rng.choice([L * 1.5, L * 3, 20.0, 7.3]))
+    start_up = float(min(max_buffer, rng.choice([0.0, L, 2 * L, 1.7])))
+    bw_lo = float(rng.choice([0.1, 0.5, 2.0]))
+    bw_hi = bw_lo * float(rng.choice([3.0, 10.0, 40.0]))
+    speed = float(rng.choice([1.0, 1.0, 0.8, 1.25]))
+    V = int(rng.integers(2, 20))
+    return dict(ladder=ladder, chunk_length=L, video_length=V, max_buffer=max_buffer,
+                start_up_length=start_up, interval=interval, weights=[4.3, 1, 1, 0.1],
+                speed=speed), (bw_lo, bw_hi)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_configurations_against_oracle(H, oracle, seed):
+    """Config-space fuzz: chunk lengths, trace intervals (shorter than the 32-addition
+    prologue, longer than a chunk, non-representable), ladders, buffer limits, speeds,
+    ragged traces with wrap-around."""
+    rng = np.random.default_rng(1000 + seed)
+    meta, (lo, hi) = _random_config(rng)
+    n_traces, N = 6, 200
+    lens = rng.integers(40, 3000, n_traces)
+    traces = [rng.uniform(lo, hi, l).astype(np.float32).astype(np.float64) for l in lens]
+    trace_id = rng.integers(0, n_traces, N).astype(np.int32)
+    offset = np.array([rng.integers(0, lens[t]) for t in trace_id], np.int32)
+    actions = rng.integers(0, len(meta["ladder"]), (N, meta["video_length"])).astype(np.int32)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
+    steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, max_ticks=4_000_000)
+    # generous tick bound: starved lanes take long
+    rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions,
+                                   max_ticks=int(fino["ticks"].max()) + 1000)
+    _check(rec, bw, fin, steps, bwo, fino)
