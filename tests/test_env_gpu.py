@@ -364,3 +364,25 @@ def test_random_configurations_against_oracle(oracle, seed):
             env.step(acts[:, s].contiguous())
         assert np.array_equal(env.history()[1].cpu().numpy().T, bw), impl
         assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10), impl
+
+
+def test_c_host_program(tmp_path):
+    """The drop-in boundary from a plain-C host (hipMalloc'd buffers, no Python, no torch):
+    tests/native/abi_c_host.c steps an episode through the C ABI and checks it against the
+    oracle library."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from oracle import oracle as O
+    so_oracle = O.build()
+    exe = str(tmp_path / "abi_c_host")
+    lib_dir = os.path.join(ROOT, "abrsimulator_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=gnu11", "-D__HIP_PLATFORM_AMD__", "-O1",
+                           os.path.join(ROOT, "tests", "native", "abi_c_host.c"),
+                           "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           "-L", lib_dir, "-labr_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-lm",
+                           "-o", exe])
+    out = subprocess.run([exe, so_oracle], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "mismatches 0" in out.stdout
