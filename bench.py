@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
+    ap.add_argument("--graph", action="store_true",
+                    help="env_random, N=1: capture one launch in a HIP graph and replay it "
+                         "(removes the host launch path; matters at --fuse 1)")
     a = ap.parse_args()
 
     import torch
@@ -213,8 +216,27 @@ def main():
             from abrsimulator_amd.sharding import ObsRewardGather
             gat = ObsRewardGather((OBS_DIM, N), (F, N), dev)
 
+        graph = None
+        if a.graph and world == 1:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                env.step_random(F, a.seed, out=bufs[0])   # warm-up on a side stream before capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                env.step_random(F, a.seed, out=bufs[0])
+
         def run(n_steps, timed):
             left, it = n_steps, 0
+            while graph is not None and left >= F:
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                graph.replay()
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    ev.append((e0, e1, F))
+                left -= F
             while left > 0:
                 f = min(F, left)
                 b = it & 1
@@ -332,6 +354,7 @@ def main():
                        "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
                        "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
                        "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
+                       "hip_graph": bool(a.graph and world == 1 and a.workload == "env_random"),
                        "auto_reset": True,
                        "collective": ("all_gather(final obs [8,N] + rewards [fuse,N]) per launch, "
                                       "overlapped" if world > 1 and not a.no_gather
