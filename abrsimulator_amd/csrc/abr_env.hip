@@ -1107,17 +1107,23 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     // ---- phase 1: harmonic predictor, one thread per lane (mpc.py:81-93) ----
     if (valid && pre == 0) {
         double n = p.hist_n[lane], S = p.hist_s[lane];
-        for (int i = 0; i < H; i++) {
-            double tp = n / S;            // history_size / sum_inverse  (:90)
-            my[3 * HB + i] = tp;
-            S = S + 1.0 / tp;             // throughput_values.append(tp): next pass sums it last
-            n = n + 1.0;
-        }
-        p.hist_n[lane] = n; p.hist_s[lane] = S;        // D9: the caller's list has grown by H
         int c = p.chunk[lane];
         int he = H;
         if (c + H > p.V) he = p.clip ? (p.V - c) : 0;  // D12
         if (he < 0) he = 0;
+        if (!(n > 0.0) || !(S > 0.0) || c < 0) {
+            // D13: empty / zero throughput history -- the reference raises ZeroDivisionError
+            // (mpc.py:88,90).  Defined here as "no decision": history untouched, action -1.
+            he = 0;
+        } else {
+            for (int i = 0; i < H; i++) {
+                double tp = n / S;            // history_size / sum_inverse  (:90)
+                my[3 * HB + i] = tp;
+                S = S + 1.0 / tp;             // throughput_values.append(tp): next pass sums it last
+                n = n + 1.0;
+            }
+            p.hist_n[lane] = n; p.hist_s[lane] = S;    // D9: the caller's list has grown by H
+        }
         heff_s[li] = he;
     }
     __syncthreads();

@@ -225,6 +225,9 @@ typedef struct abr_mpc_config {
  *  flat arg-min index; best_J_out_dev (nullable) float64 [n_lanes];
  *  lane_mask_dev (nullable): lanes with a zero byte are skipped entirely
  *  (no history mutation, outputs untouched).
+ *  Lanes the reference would raise on report action -1 (flat -1, J NaN) and keep their
+ *  history: an empty or zero history (ZeroDivisionError, mpc.py:88,90, D13) and, without
+ *  clip_horizon, chunk + horizon > video_length (IndexError, mpc.py:126, D12).
  */
 int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
                    const int32_t *prev_bitrate_dev, const double *buffer_dev, double *hist_n_dev,

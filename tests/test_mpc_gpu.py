@@ -199,3 +199,17 @@ def test_mpc_drives_env_rollout(oracle):
         steps, bw, acts, fin = oracle.env_episode_policy(ecfg, traces[lane % 16], 0, policy)
         assert np.array_equal(acts, gpu_actions[lane]), (lane, acts, gpu_actions[lane])
         assert np.isclose(fin["qoe"], qoe[lane], rtol=1e-10)
+
+
+def test_empty_history_is_a_defined_no_decision():
+    """D13: mpc.py:88,90 divide by an empty / zero history.  Defined: action -1, history untouched."""
+    B, H, V, L, mb = 6, 5, 20, 4.0, 20.0
+    lad = np.array([0.3, 0.75, 1.2, 1.85, 2.85, 4.3])
+    br = np.tile(lad, (V, 1)); sz = br * L
+    chunk = np.array([3, 3, 3], np.int32); prev = np.array([1, 1, 1], np.int32)
+    buf = np.array([5.0, 5.0, 5.0]); hn = np.array([0.0, 4.0, 3.0]); hs = np.array([0.0, 2.0, 0.0])
+    ctl, ci = _controller(br, sz, L, mb, 4.3, 1.0, 0.0, H, chunk, prev, buf, hn, hs)
+    a = ctl.next_bitrate(want_details=True).cpu().numpy()
+    assert a[0] == -1 and a[2] == -1 and a[1] >= 0
+    assert ci.hist_n.cpu().numpy().tolist() == [0.0, 9.0, 3.0]
+    assert np.isnan(ctl.last_J.cpu().numpy()[[0, 2]]).all() and int(ctl.last_flat[0]) == -1
