@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=480)
     ap.add_argument("--fuse", type=int, default=48, help="chunk decisions per kernel launch (48 = one episode)")
     ap.add_argument("--lanes-per-gpu", type=int, default=65536)
+    ap.add_argument("--total-lanes", type=int, default=0,
+                    help="strong scaling: split this many lanes over the GPUs (e.g. 1048576, the "
+                         "BASELINE.json scaling curve) instead of a fixed count per GPU")
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
     ap.add_argument("--seed", type=int, default=1)
@@ -182,9 +185,15 @@ def main():
     import abrsimulator_amd as A
     from abrsimulator_amd._lib import OBS_DIM
 
-    N = a.lanes_per_gpu
+    from abrsimulator_amd.sharding import shard_range
+    if a.total_lanes:
+        lane0, N = shard_range(a.total_lanes, world, rank)       # strong scaling
+        if a.total_lanes % world:
+            raise SystemExit("--total-lanes must divide evenly over the GPUs (equal gather shapes)")
+    else:
+        N = a.lanes_per_gpu                                      # weak scaling (default)
+        lane0 = rank * N
     traces = synth_traces(a.mixed_traces)
-    lane0 = rank * N
     tid, off = lane_assignment(lane0, N, traces)
     mpd = A.MPD(V, L, MAX_BUFFER, START_UP, A.Chunk(LADDER))
     env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
@@ -348,7 +357,7 @@ def main():
         line = {
             "metric": metric, "value": total_units / elapsed, "unit": unit, "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if a.total_lanes else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
                        "fuse": a.fuse if a.workload == "env_random" else 1,
                        "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
