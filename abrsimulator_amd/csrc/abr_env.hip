@@ -1,20 +1,21 @@
 // abr_env.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/abr_env.h.
 //
 // Hot path restated from the reference (file:line into Elliotshui/ABRSimulator):
-//   K1 env_advance   Simulator.py:135-208   the dt = 0.01 s tick loop, one lane per thread
-//   K2 env_reset     Simulator.py:95-133    state init + idle ticks to the first ABR call site
-//   K3 mpc_select    mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H lookahead
-//   K4 episode_qoe   Simulator.py:79-86
+//   K1/K2 env_jump_kernel<MODE>     Simulator.py:95-133,135-208   event-driven (default): the
+//         tick loop's float64 sequences advanced in exact closed form (abr_lane_jump.h,
+//         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout
+//   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
+//   K3    mpc_select_kernel<H, B>   mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H
+//   K4    episode_qoe_kernel        Simulator.py:79-86
 //
-// Exactness contract (DESIGN.md "Numerics"): every quantity that feeds a
-// decision in the reference (download_size >= target, buffer_level vs 0 /
-// max_buffer / start_up_length, int(global_time / x), play_length >= L) is
-// reproduced bit-for-bit: the lane-specific ones (downloaded_size,
-// buffer_level) as the same serial float64 additions, the lane-independent ones
-// (global_time and everything that is "k additions of dt starting from 0")
-// through tick tables computed once on the host in float64.  Compile with
-// -ffp-contract=off: an FMA would round bandwidth*dt + downloaded_size once
-// instead of twice (Simulator.py:160).
+// Exactness contract: every quantity that feeds a decision in the
+// reference (downloaded_size >= target, buffer_level vs 0 / max_buffer / start_up_length,
+// int(global_time / x), play_length >= L) is reproduced bit-for-bit: the lane-specific
+// ones (downloaded_size, buffer_level) as the float64 value the serial additions produce,
+// the lane-independent ones (global_time and everything that is "k additions of dt
+// starting from 0") through tick tables computed once on the host in float64
+// (abr_tick_tables.h).  Compile with -ffp-contract=off: an FMA would round
+// bandwidth*dt + downloaded_size once instead of twice (Simulator.py:160).
 #include <hip/hip_runtime.h>
 
 #include <climits>
