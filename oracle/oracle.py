@@ -90,7 +90,8 @@ def pack_traces(traces):
     return np.ascontiguousarray(flat), off, lens
 
 
-def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=None):
+def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=None,
+              want_steps=True):
     """Replay episodes. traces: list of arrays. actions: [N, V] int32.  speeds: optional
     per-lane constant play speeds [N] (default: cfg.speed for every lane).
     Returns (steps[N,V] STEP_DTYPE, bw[N,V], final[N] FINAL_DTYPE, total_ticks)."""
@@ -100,22 +101,23 @@ def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=
     actions = np.ascontiguousarray(actions, np.int32)
     N, V = actions.shape
     assert V == cfg.video_length
-    steps = np.zeros((N, V), STEP_DTYPE)
+    steps = np.zeros((N, V), STEP_DTYPE) if want_steps else None
     bw = np.zeros((N, V), np.float64)
     fin = np.zeros(N, FINAL_DTYPE)
+    sp = steps.ctypes.data_as(C.c_void_p) if want_steps else None
     if speeds is not None:
         speeds = np.ascontiguousarray(speeds, np.float64)
         assert speeds.shape == (N,)
         rc = lib().oracle_env_batch_speeds(
             C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
             _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32),
-            _p(speeds, C.c_double), C.c_int32(N), steps.ctypes.data_as(C.c_void_p),
+            _p(speeds, C.c_double), C.c_int32(N), sp,
             _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p), C.c_int64(max_ticks))
     else:
         rc = lib().oracle_env_batch(
             C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
             _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32), C.c_int32(N),
-            steps.ctypes.data_as(C.c_void_p), _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p),
+            sp, _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p),
             C.c_int64(max_ticks))
     if rc < 0:
         raise RuntimeError(f"oracle_env_batch failed: {rc}")
