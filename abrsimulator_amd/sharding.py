@@ -25,12 +25,21 @@ def shard_range(total_lanes: int, world_size: int, rank: int) -> Tuple[int, int]
     return lane0, n
 
 
-def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int]):
+def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int], xcd_groups: int = 0):
     """Deterministic global-lane -> (trace_id, start_offset) map used by bench.py:
-    lane i reads trace i % n_traces from offset (i * 2654435761 mod 2^32) % len."""
+    lane i reads trace i % n_traces from offset (i * 2654435761 mod 2^32) % len.
+    xcd_groups = 8 makes the map XCD-aware: workgroup w = lane // 64 runs on XCD group
+    w % 8 (workgroups are dealt round-robin over the 8 XCDs), and that group only reads
+    traces t with t % 8 == w % 8, so each XCD's L2 holds 1/8 of the trace table."""
     i = np.arange(lane0, lane0 + n, dtype=np.uint64)
     lens = np.asarray(trace_lens, np.uint64)
-    tid = (i % np.uint64(len(lens))).astype(np.int32)
+    if xcd_groups and len(lens) % xcd_groups == 0:
+        g = np.uint64(xcd_groups)
+        per = np.uint64(len(lens) // xcd_groups)
+        w = (i - np.uint64(lane0)) // np.uint64(64)
+        tid = (((i // g) % per) * g + (w % g)).astype(np.int32)
+    else:
+        tid = (i % np.uint64(len(lens))).astype(np.int32)
     off = ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % lens[tid]).astype(np.int32)
     return tid, off
 
