@@ -92,3 +92,19 @@ def test_two_rank_gather_equals_unsharded(tmp_path):
     full_o, full_r = np.load(out + "_o.npy"), np.load(out + "_r.npy")
     ref_o, ref_r = _rollout(0, TOTAL, _traces())
     assert np.array_equal(full_o, ref_o) and np.array_equal(full_r, ref_r)
+
+
+def test_xcd_aware_lane_assignment():
+    from abrsimulator_amd.sharding import lane_assignment
+    lens = [1000] * 1024
+    tid, off = lane_assignment(0, 65536, lens, xcd_groups=8)
+    assert tid.min() == 0 and tid.max() == 1023 and (off >= 0).all() and (off < 1000).all()
+    w = np.arange(65536) // 64
+    assert ((tid % 8) == (w % 8)).all()                 # workgroup w reads its XCD group's traces only
+    assert len(np.unique(tid)) == 1024                  # every trace is still used
+    # a shard of a larger job keeps the property relative to its own workgroups
+    tid2, _ = lane_assignment(131072, 4096, lens, xcd_groups=8)
+    assert ((tid2 % 8) == ((np.arange(4096) // 64) % 8)).all()
+    # falls back to i % n_traces when the table does not split evenly
+    tid3, _ = lane_assignment(0, 100, [10] * 7, xcd_groups=8)
+    assert (tid3 == np.arange(100) % 7).all()
