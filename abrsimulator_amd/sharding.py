@@ -36,8 +36,10 @@ def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int], xcd_groups: i
     if xcd_groups and len(lens) % xcd_groups == 0:
         g = np.uint64(xcd_groups)
         per = np.uint64(len(lens) // xcd_groups)
-        w = (i - np.uint64(lane0)) // np.uint64(64)
-        tid = (((i // g) % per) * g + (w % g)).astype(np.int32)
+        loc = i - np.uint64(lane0)
+        w = loc // np.uint64(64)                       # workgroup (one wave of 64 lanes)
+        q = (w // g) * np.uint64(64) + loc % np.uint64(64)   # lane's rank inside its XCD group
+        tid = ((q % per) * g + (w % g)).astype(np.int32)
     else:
         tid = (i % np.uint64(len(lens))).astype(np.int32)
     off = ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % lens[tid]).astype(np.int32)

@@ -50,10 +50,10 @@ def synth_traces(mixed=False):
 
 
 def lane_assignment(lane0, n, traces):
-    # XCD-aware by default: workgroup w only reads traces t with t % 8 == w % 8, so each XCD's
-    # L2 holds 1/8 of the 8 MB trace table (+0.4 % measured; ABR_XCD_GROUPS=0 for i % n_traces)
+    # lane i -> trace i % n_traces.  ABR_XCD_GROUPS=8 selects the XCD-aware map
+    # (workgroup w only reads traces t with t % 8 == w % 8); measured: no difference
     from abrsimulator_amd.sharding import lane_assignment as la
-    return la(lane0, n, [len(t) for t in traces], xcd_groups=int(os.environ.get("ABR_XCD_GROUPS", "8")))
+    return la(lane0, n, [len(t) for t in traces], xcd_groups=int(os.environ.get("ABR_XCD_GROUPS", "0")))
 
 
 def host_cores():
