@@ -33,7 +33,7 @@
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
-constexpr int kPrologue = 32;       // plain additions at the start of a download (see lanej_step)
+constexpr int kPrologue = 16;       // plain additions at the start of a download (see lanej_step)
 
 struct Tables {
     const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
