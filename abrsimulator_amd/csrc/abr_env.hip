@@ -58,6 +58,7 @@ extern "C" const char *abr_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------
 constexpr double kDt = 0.01;  // Simulator.py:133
 constexpr int kFlagStartUp = 1, kFlagBufEmpty = 2, kFlagBufFull = 4;
+constexpr int kFlagArmed = 8;    // the lane has been reset at least once since abr_env_create
 
 struct EnvParams {
     // config
@@ -65,6 +66,7 @@ struct EnvParams {
     int32_t play_ticks_per_chunk;  // P: first n with n-fold sum of speed*dt >= chunk_length (:185)
     int32_t n_intervals;           // entries in interval_tick minus sentinel
     int32_t t_block;               // ticks per block of the tick loop (<= shortest interval)
+    int32_t n_traces;              // rows of trace_off / trace_len (range check of reset's trace ids)
     double chunk_length, max_buffer, start_up_length;
     double wr, wv, ws, wl;
     double sd;                     // speed * dt, the product the reference forms each tick (:182)
@@ -98,6 +100,8 @@ struct abr_env {
     abr_env_config cfg;
     size_t workspace_bytes;
     int impl;   // 0 = event-driven kernels (default), 1 = tick-by-tick kernels (cross-check)
+    const double *pending_speeds;   // abr_env_set_lane_speeds: latched into p.lane_speeds by the next full reset
+    bool speeds_dirty;
 };
 
 // ---------------------------------------------------------------------------
@@ -228,7 +232,7 @@ __device__ inline void lane_store(const Lane &s, const EnvParams &p, int64_t i) 
     p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
     p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
-                           (s.bf ? kFlagBufFull : 0));
+                           (s.bf ? kFlagBufFull : 0) | kFlagArmed);
 }
 
 __device__ inline void write_obs(const Lane &s, const EnvParams &p, int64_t i, float *obs,
@@ -272,11 +276,17 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
         if (MODE == 0) {
             if (lane_mask && !lane_mask[i]) { active = false; touched = false; }
             if (active) {
-                const int32_t t = trace_id_in[i];
+                int32_t t = trace_id_in[i];
                 offset0 = offset_in ? offset_in[i] : 0;
+                // a trace id / start offset outside the tables: the lane is frozen with
+                // ABR_DONE_BADARG instead of reading out of bounds (it runs on trace 0, unseen)
+                if (t < 0 || t >= p.n_traces || offset0 < 0) { done |= ABR_DONE_BADARG; t = 0; offset0 = 0; }
+                // a re-armed lane starts a NEW episode of the counter-based policy
+                episode_no = (p.flags[i] & kFlagArmed) ? p.episode_no[i] + 1 : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
                 lane_init(s, p, offset0);
+                if (done) { active = false; s.running = false; }
             }
         } else {
             done = p.done[i];
@@ -490,7 +500,7 @@ __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i
     p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
     p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
-                           (s.bf ? kFlagBufFull : 0));
+                           (s.bf ? kFlagBufFull : 0) | kFlagArmed);
     if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
 }
 
@@ -530,13 +540,19 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
         if (MODE == 0) {
             if (lane_mask && !lane_mask[i]) { active = false; touched = false; }
             if (active) {
-                const int32_t t = trace_id_in[i];
+                int32_t t = trace_id_in[i];
                 offset0 = offset_in ? offset_in[i] : 0;
+                // a trace id / start offset outside the tables: the lane is frozen with
+                // ABR_DONE_BADARG instead of reading out of bounds (it sits on trace 0, unseen)
+                const bool bad = t < 0 || t >= p.n_traces || offset0 < 0;
+                if (bad) { done |= ABR_DONE_BADARG; t = 0; offset0 = 0; }
+                // a re-armed lane starts a NEW episode of the counter-based policy
+                episode_no = (p.flags[i] & kFlagArmed) ? p.episode_no[i] + 1 : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
                 s.sd = p.lane_speeds ? p.lane_speeds[i] * kDt : p.sd;     // play_speed * dt (:182)
                 abrx::lanej_init(s, tb, offset0);
-                if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
+                if (!bad && !abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                 write_obs_j(s, p, i, obs_out, 0.0);
             }
         } else {
@@ -703,12 +719,19 @@ struct Layout {
     int32_t max_ticks, n_intervals;
 };
 
-static int32_t default_max_ticks(const abr_env_config *c) {
+// Default per-episode tick bound: 32 x the live-stream minimum V * ceil(L/dt), capped at 16e6
+// ticks (a 128 MB G table) but never below 2 x the minimum; compute_layout rejects a bound
+// under which no episode could finish.
+static double min_episode_ticks(const abr_env_config *c) {
+    return ((double)c->video_length + 1.0) * ceil(c->chunk_length / kDt);
+}
+static double default_max_ticks(const abr_env_config *c) {
     double per_chunk = ceil(c->chunk_length / kDt);
     double mt = 32.0 * c->video_length * per_chunk;
     if (mt > 16.0e6) mt = 16.0e6;
+    if (mt < 2.0 * min_episode_ticks(c)) mt = 2.0 * min_episode_ticks(c);
     if (mt < 1024) mt = 1024;
-    return (int32_t)mt;
+    return mt;
 }
 
 static int validate_cfg(const abr_env_config *c) {
@@ -732,7 +755,14 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     int rc = validate_cfg(c);
     if (rc) return rc;
     if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
-    int32_t mt = c->max_ticks > 0 ? c->max_ticks : default_max_ticks(c);
+    const double mtd = c->max_ticks > 0 ? (double)c->max_ticks : default_max_ticks(c);
+    if (mtd > 256.0e6)
+        return fail(ABR_E_UNSUPPORTED, "video_length %d x chunk_length %g s needs a %g-entry tick table",
+                    c->video_length, c->chunk_length, mtd);
+    if (mtd < min_episode_ticks(c))
+        return fail(ABR_E_INVALID, "max_ticks %g is below (video_length + 1) * ceil(chunk_length / dt) = %g: "
+                    "every lane would end in ABR_DONE_TIMEOUT", mtd, min_episode_ticks(c));
+    const int32_t mt = (int32_t)mtd;
     double n_iv = (double)mt * kDt / c->interval + 4.0;
     if (n_iv > 32.0e6)
         return fail(ABR_E_UNSUPPORTED, "interval %g s needs a %g-entry tick table", c->interval, n_iv);
@@ -803,7 +833,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     EnvParams &p = e->p;
     p.n_rates = cfg->n_rates; p.video_length = cfg->video_length; p.max_ticks = mt;
     p.auto_reset = cfg->auto_reset; p.play_ticks_per_chunk = P; p.n_intervals = L.n_intervals;
-    p.t_block = t_block;
+    p.t_block = t_block; p.n_traces = n_traces;
     p.chunk_length = cfg->chunk_length; p.max_buffer = cfg->max_buffer;
     p.start_up_length = cfg->start_up_length;
     p.wr = cfg->rebuffer_weight; p.wv = cfg->variance_weight; p.ws = cfg->startup_weight;
@@ -857,7 +887,7 @@ extern "C" int abr_env_destroy(abr_env *env) {
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (impl != 0 && impl != 1) return fail(ABR_E_INVALID, "impl must be 0 (jump) or 1 (tick)");
-    if (impl == 1 && env->p.lane_speeds)
+    if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
     return ABR_OK;
@@ -868,7 +898,10 @@ extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (speeds_dev && env->impl)
         return fail(ABR_E_UNSUPPORTED, "per-lane speeds need the event-driven kernels (impl 0)");
-    env->p.lane_speeds = speeds_dev;
+    // latched by the next FULL abr_env_reset: until then the running episodes keep the
+    // speeds (and the carried play_time) they were started with
+    env->pending_speeds = speeds_dev;
+    env->speeds_dirty = true;
     return ABR_OK;
 }
 
@@ -886,6 +919,13 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
                              float *obs_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!trace_id_dev) return fail(ABR_E_INVALID, "trace_id_dev is NULL");
+    if (env->speeds_dirty) {
+        if (lane_mask_dev)
+            return fail(ABR_E_INVALID, "abr_env_set_lane_speeds takes effect at a reset of ALL lanes "
+                        "(lane_mask_dev must be NULL for the first reset after it)");
+        env->p.lane_speeds = env->pending_speeds;
+        env->speeds_dirty = false;
+    }
     hipLaunchKernelGGL(env->impl ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, nullptr, trace_id_dev, start_offset_dev,
                        lane_mask_dev, obs_out_dev, nullptr, nullptr, nullptr, 0, 0ull);
@@ -1096,6 +1136,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     double *bestJ = lds + LPB * per_lane;
     int32_t *bestF = (int32_t *)(bestJ + LPB * T);
     __shared__ int32_t heff_s[16];
+    __shared__ int32_t prev_s[16];    // previous_bitrate as the index Python would use (mpc.py:132,148)
 
     const int tid = threadIdx.x;
     const int li = tid / T;               // lane in block
@@ -1112,9 +1153,17 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         int he = H;
         if (c + H > p.V) he = p.clip ? (p.V - c) : 0;  // D12
         if (he < 0) he = 0;
-        if (!(n > 0.0) || !(S > 0.0) || c < 0) {
+        // R[0] = previous_bitrate indexes bitrates[i] (mpc.py:132,148): Python wraps -B..-1 to
+        // the top of the ladder (the env's "no previous chunk" value -1 -> the highest rate) and
+        // raises IndexError outside [-B, B)
+        int pv = p.prev[lane];
+        const bool prev_ok = (pv >= -B) && (pv < B);
+        if (pv < 0) pv += B;
+        prev_s[li] = prev_ok ? pv : 0;
+        if (!(n > 0.0) || !(S > 0.0) || c < 0 || !prev_ok) {
             // D13: empty / zero throughput history -- the reference raises ZeroDivisionError
-            // (mpc.py:88,90).  Defined here as "no decision": history untouched, action -1.
+            // (mpc.py:88,90); likewise an out-of-range previous_bitrate (IndexError).  Defined
+            // here as "no decision": history untouched, action -1.
             he = 0;
         } else {
             for (int i = 0; i < H; i++) {
@@ -1155,7 +1204,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B;
         t.heff = heff_s[li];
         double q = 0.0, v = 0.0, rb = 0.0, buf = p.buffer[lane];
-        int prev_r = p.prev[lane];
+        int prev_r = prev_s[li];
         int32_t flat = 0;
         bool ok = true, is_leaf = false;
         // digits of the prefix, most significant first
@@ -1216,7 +1265,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
                 MpcLds t;
                 t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
                 t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = he;
-                bf = mpc_resolve_group(t, H, bf, p.prev[lane], p.buffer[lane], bx);
+                bf = mpc_resolve_group(t, H, bf, prev_s[li], p.buffer[lane], bx);
             }
             int32_t lead = 1;
             for (int i = 1; i < he; i++) lead *= B;
@@ -1317,7 +1366,7 @@ __global__ void mpc_grid_kernel(int B, int H, int V, double L, double max_buffer
     {
         int64_t t = f;
         for (int i = H; i >= 1; i--) { R[i] = (int)(t % B); t /= B; }
-        R[0] = prev;
+        R[0] = prev < 0 ? prev + B : prev;     // Python's negative index (mpc.py:148)
     }
     double q = 0.0, v = 0.0, rb = 0.0, buf = buffer;
     for (int i = 0; i < H; i++) {
@@ -1348,6 +1397,9 @@ extern "C" int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk,
     if (rc) return rc;
     if (!pred_dev || !br_table_dev || !sz_table_dev || !J_out_dev)
         return fail(ABR_E_INVALID, "NULL device pointer");
+    if (prev_bitrate < -cfg->n_rates || prev_bitrate >= cfg->n_rates)
+        return fail(ABR_E_INVALID, "previous_bitrate %d outside [-%d, %d) (mpc.py:148 raises IndexError)",
+                    prev_bitrate, cfg->n_rates, cfg->n_rates);
     if (chunk < 0 || chunk + cfg->horizon > cfg->video_length)
         return fail(ABR_E_INVALID, "chunk %d + horizon %d exceeds video_length %d (mpc.py:126 raises)",
                     chunk, cfg->horizon, cfg->video_length);

@@ -32,8 +32,29 @@ class MPD:
     chunks: object = None
 
     def ladder(self) -> List[float]:
-        c = self.chunks[0] if isinstance(self.chunks, (list, tuple)) else self.chunks
-        return [float(b) for b in c.bitrates]
+        """The single ladder Simulator.run() indexes (Simulator.py:82,156).  A per-chunk
+        MPD whose lines differ has no single ladder: raises instead of silently using
+        chunk 0's (use bitrate_table() for the per-chunk form)."""
+        if isinstance(self.chunks, (list, tuple)):
+            first = [float(b) for b in self.chunks[0].bitrates]
+            for i, c in enumerate(self.chunks):
+                if [float(b) for b in c.bitrates] != first:
+                    raise ValueError(f"MPD chunk {i} has a different bitrate ladder than chunk 0: "
+                                     "this MPD has no single ladder")
+            return first
+        return [float(b) for b in self.chunks.bitrates]
+
+    def uniform(self) -> bool:
+        """True when every chunk carries the same bitrate ladder."""
+        try:
+            self.ladder()
+            return True
+        except ValueError:
+            return False
+
+    def bitrate_table(self) -> List[List[float]]:
+        """[video_length][n_rates] bitrates, one row per chunk."""
+        return [[float(b) for b in c.bitrates] for c in self.chunk_list()]
 
     def chunk_list(self) -> List[Chunk]:
         if isinstance(self.chunks, (list, tuple)):

@@ -112,6 +112,12 @@ class BatchedABREnv:
     def _stream(self):
         return _lib.current_stream(self.device)
 
+    def _call(self, fn, *args):
+        """One C-ABI call with self.device current: the library launches on the stream it is
+        handed, and HIP launches go to the CURRENT device."""
+        with torch.cuda.device(self.device):
+            _lib.check(fn(*args, self._stream()))
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.abr_env_destroy(self._h)
@@ -149,17 +155,16 @@ class BatchedABREnv:
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        _lib.check(self.lib.abr_env_reset(self._h, _lib.ptr(self.trace_id),
-                                          _lib.ptr(self.start_offset), _lib.ptr(m),
-                                          _lib.ptr(self.obs), self._stream()))
+        self._call(self.lib.abr_env_reset, self._h, _lib.ptr(self.trace_id),
+                   _lib.ptr(self.start_offset), _lib.ptr(m), _lib.ptr(self.obs))
         return self.obs
 
     def step(self, actions):
         """One chunk per lane.  Returns (obs f32[OBS_DIM,N], reward f32[N], done u8[N]);
         the tensors are reused across calls."""
         a = self._i32(actions, "actions")
-        _lib.check(self.lib.abr_env_step(self._h, _lib.ptr(a), _lib.ptr(self.obs),
-                                         _lib.ptr(self.reward), _lib.ptr(self.done), self._stream()))
+        self._call(self.lib.abr_env_step, self._h, _lib.ptr(a), _lib.ptr(self.obs),
+                   _lib.ptr(self.reward), _lib.ptr(self.done))
         return self.obs, self.reward, self.done
 
     # the Pensieve-style name BASELINE.json uses for the same call
@@ -176,10 +181,9 @@ class BatchedABREnv:
                 done=torch.empty(n, self.n_lanes, dtype=torch.uint8, device=self.device),
                 actions=(torch.empty(n, self.n_lanes, dtype=torch.int32, device=self.device)
                          if want_actions else None))
-        _lib.check(self.lib.abr_env_step_random(
-            self._h, n, C.c_uint64(int(seed) & (2 ** 64 - 1)), _lib.ptr(out.get("obs")),
-            _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")), _lib.ptr(out.get("actions")),
-            self._stream()))
+        self._call(self.lib.abr_env_step_random, self._h, n, C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                   _lib.ptr(out.get("obs")), _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")),
+                   _lib.ptr(out.get("actions")))
         return out
 
     # -- exact state -------------------------------------------------------
@@ -187,13 +191,13 @@ class BatchedABREnv:
         """dict of float64 [N] tensors: everything the reference's run() frame holds
         at the call site (rows: _lib.F64_ROWS)."""
         out = torch.empty(F64_DIM, self.n_lanes, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.abr_env_observe_f64(self._h, _lib.ptr(out), self._stream()))
+        self._call(self.lib.abr_env_observe_f64, self._h, _lib.ptr(out))
         return {k: out[i] for i, k in enumerate(F64_ROWS)}
 
     def episode_qoe(self):
         """calculate_qoe (Simulator.py:79-86) of each lane's (last) finished episode, float64 [N]."""
         out = torch.empty(self.n_lanes, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.abr_env_episode_qoe(self._h, _lib.ptr(out), self._stream()))
+        self._call(self.lib.abr_env_episode_qoe, self._h, _lib.ptr(out))
         return out
 
     def state_view(self):

@@ -93,11 +93,12 @@ class BatchedMPCController:
                       (ci.hist_sum_inv, torch.float64)):
             if t.dtype != dt or t.device.type != "cuda":
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
-        _lib.check(self.lib.abr_mpc_select(
-            C.byref(cfg), _lib.ptr(ci.chunk_number), _lib.ptr(ci.previous_bitrate),
-            _lib.ptr(ci.buffer_level), _lib.ptr(ci.hist_n), _lib.ptr(ci.hist_sum_inv),
-            _lib.ptr(br), _lib.ptr(sz), _lib.ptr(mask), _lib.ptr(action), _lib.ptr(flat),
-            _lib.ptr(J), N, _lib.current_stream(self.device)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.abr_mpc_select(
+                C.byref(cfg), _lib.ptr(ci.chunk_number), _lib.ptr(ci.previous_bitrate),
+                _lib.ptr(ci.buffer_level), _lib.ptr(ci.hist_n), _lib.ptr(ci.hist_sum_inv),
+                _lib.ptr(br), _lib.ptr(sz), _lib.ptr(mask), _lib.ptr(action), _lib.ptr(flat),
+                _lib.ptr(J), N, _lib.current_stream(self.device)))
         self.last_flat, self.last_J = flat, J
         return action
 
@@ -107,9 +108,10 @@ class BatchedMPCController:
         cfg = self.config()
         pred = torch.as_tensor(predicted_bandwidths, dtype=torch.float64, device=self.device).contiguous()
         out = torch.empty(cfg.n_rates ** cfg.horizon, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.abr_mpc_objective_grid(
-            C.byref(cfg), int(chunk), int(prev_bitrate), float(buffer_level), _lib.ptr(pred),
-            _lib.ptr(br), _lib.ptr(sz), _lib.ptr(out), _lib.current_stream(self.device)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.abr_mpc_objective_grid(
+                C.byref(cfg), int(chunk), int(prev_bitrate), float(buffer_level), _lib.ptr(pred),
+                _lib.ptr(br), _lib.ptr(sz), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
 

@@ -36,9 +36,11 @@ def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int], xcd_groups: i
     if xcd_groups and len(lens) % xcd_groups == 0:
         g = np.uint64(xcd_groups)
         per = np.uint64(len(lens) // xcd_groups)
-        loc = i - np.uint64(lane0)
-        w = loc // np.uint64(64)                       # workgroup (one wave of 64 lanes)
-        q = (w // g) * np.uint64(64) + loc % np.uint64(64)   # lane's rank inside its XCD group
+        # GLOBAL lane ids, so an N-shard run keeps the 1-shard lane -> trace map; the
+        # workgroup of a shard-local lane equals the global one (mod 8) whenever lane0 is a
+        # multiple of 512, which equal shards of the bench sizes are
+        w = i // np.uint64(64)                         # workgroup (one wave of 64 lanes)
+        q = (w // g) * np.uint64(64) + i % np.uint64(64)     # lane's rank inside its XCD group
         tid = ((q % per) * g + (w % g)).astype(np.int32)
     else:
         tid = (i % np.uint64(len(lens))).astype(np.int32)
@@ -46,46 +48,71 @@ def lane_assignment(lane0: int, n: int, trace_lens: Sequence[int], xcd_groups: i
     return tid, off
 
 
+def make_slab(n_steps: int, obs_dim: int, n_lanes: int, device):
+    """One contiguous float32 slab laid out [obs: n_steps x obs_dim x N | reward: n_steps x N].
+    The kernel writes obs and reward through the two views; `send` -- the LAST step's
+    observation followed by all rewards -- is contiguous inside the slab, so the collective
+    ships it without a packing copy.  Returns (slab, obs, reward, send)."""
+    n_obs = n_steps * obs_dim * n_lanes
+    slab = torch.empty(n_obs + n_steps * n_lanes, dtype=torch.float32, device=device)
+    obs = slab[:n_obs].view(n_steps, obs_dim, n_lanes)
+    reward = slab[n_obs:].view(n_steps, n_lanes)
+    send = slab[n_obs - obs_dim * n_lanes:]
+    return slab, obs, reward, send
+
+
 class ObsRewardGather:
-    """Double-buffered all-gather of (obs, reward) slabs, overlapped with the next
-    launch on a side stream when the tensors live on a GPU."""
+    """THE one collective of the path: a double-buffered all-gather of each rank's packed
+    (obs, reward) slab -- a single all_gather_into_tensor per launch (RCCL over xGMI on the
+    GPU box; gloo in the CPU tests) -- issued on a side stream so that it overlaps the next
+    launch when the tensors live on a GPU.
+
+    obs_shape / reward_shape describe one rank's part, e.g. (OBS_DIM, N) and (F, N): the
+    sent slab is obs.numel() + reward.numel() float32 values, obs first (make_slab)."""
 
     def __init__(self, obs_shape, reward_shape, device, group=None, n_buffers=2):
         self.group = group
         self.world = dist.get_world_size(group)
         self.device = torch.device(device)
-        # flat [world * shape[0], ...] outputs: the concatenating form every backend accepts
         self.obs_shape, self.reward_shape = tuple(obs_shape), tuple(reward_shape)
-        self.obs = [torch.empty((self.world * obs_shape[0],) + tuple(obs_shape[1:]),
-                                dtype=torch.float32, device=device) for _ in range(n_buffers)]
-        self.reward = [torch.empty((self.world * reward_shape[0],) + tuple(reward_shape[1:]),
-                                   dtype=torch.float32, device=device) for _ in range(n_buffers)]
+        self.n_obs = int(np.prod(self.obs_shape))
+        self.n_rew = int(np.prod(self.reward_shape))
+        self.numel = self.n_obs + self.n_rew
+        self.out = [torch.empty(self.world * self.numel, dtype=torch.float32, device=device)
+                    for _ in range(n_buffers)]
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
         self.pending = [None] * n_buffers
+        self.n_collectives = 0
 
     def wait_free(self, b):
         """Before the producer overwrites source slab b again."""
         if self.cuda and self.pending[b] is not None:
             torch.cuda.current_stream(self.device).wait_event(self.pending[b])
 
-    def gather(self, b, obs, reward):
-        """Enqueue the all-gather of slab b (obs/reward are this rank's shard)."""
+    def gather(self, b, send):
+        """Enqueue the all-gather of this rank's packed slab into buffer b.  Returns
+        (obs [world, *obs_shape], reward [world, *reward_shape]) views of the result."""
+        if send.numel() != self.numel or send.dtype != torch.float32 or not send.is_contiguous():
+            raise ValueError(f"send slab must be {self.numel} contiguous float32 values")
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record()
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
-                dist.all_gather_into_tensor(self.obs[b], obs, group=self.group)
-                dist.all_gather_into_tensor(self.reward[b], reward, group=self.group)
+                dist.all_gather_into_tensor(self.out[b], send, group=self.group)
                 fin = torch.cuda.Event()
                 fin.record()
             self.pending[b] = fin
         else:
-            dist.all_gather_into_tensor(self.obs[b], obs, group=self.group)
-            dist.all_gather_into_tensor(self.reward[b], reward, group=self.group)
-        return (self.obs[b].view((self.world,) + self.obs_shape),
-                self.reward[b].view((self.world,) + self.reward_shape))
+            dist.all_gather_into_tensor(self.out[b], send, group=self.group)
+        self.n_collectives += 1
+        return self.split(self.out[b])
+
+    def split(self, gathered):
+        g = gathered.view(self.world, self.numel)
+        return (g[:, :self.n_obs].reshape((self.world,) + self.obs_shape),
+                g[:, self.n_obs:].reshape((self.world,) + self.reward_shape))
 
     def finish(self):
         if self.cuda:

@@ -16,6 +16,7 @@ once: the build takes a constant playback speed (D8: no speed controller ships).
 """
 import torch
 
+from . import _lib
 from .datamodel import MPD, NetworkInfo, QOEMetric
 from .env import BatchedABREnv
 from .traces import load_mpd_file, load_network_info
@@ -82,6 +83,8 @@ class Simulator(object):
             a = self.abr_controller.get_next_bitrate(chunk_id, prev_bitrates, prev_bandwidths,
                                                      buffer_level)
             env.step(torch.as_tensor(a, device=env.device).to(torch.int32))
-        if not bool((done != 0).all()):
-            raise RuntimeError("episodes did not finish in video_length decisions")
+        if not bool((done == _lib.DONE_EPISODE).all()):
+            bad = int((done != _lib.DONE_EPISODE).sum())
+            raise RuntimeError(f"{bad} lanes did not finish cleanly in video_length decisions "
+                               "(bad action, bad reset argument or max_ticks timeout)")
         return env.episode_qoe()

@@ -52,6 +52,8 @@ extern "C" {
 #define ABR_DONE_EPISODE 0x1    /* chunk_id >= video_length  (Simulator.py:207-208) */
 #define ABR_DONE_TIMEOUT 0x2    /* hit config.max_ticks before finishing */
 #define ABR_DONE_BADACT 0x4     /* action outside [0, n_rates): lane frozen (the reference raises IndexError) */
+#define ABR_DONE_BADARG 0x8     /* abr_env_reset got a trace id outside [0, n_traces) or a negative start
+                                   offset for this lane: lane frozen, nothing read out of bounds */
 
 /* float32 observation rows written by reset/step: the four arguments of
  * get_next_bitrate (Simulator.py:155) first, then run() locals at that instant */
@@ -126,9 +128,12 @@ int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
 
 /* One constant play speed per lane instead of config.speed (what a per-lane speed
  * controller that always answers the same value would do, Simulator.py:176-177).
- * speeds_dev: float64 [n_lanes], > 0, must stay valid until the next abr_env_reset has run;
- * takes effect at that reset.  NULL restores the single speed.  Event-driven kernels only. */
-int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);
+ * speeds_dev: float64 [n_lanes], > 0, must stay valid from this call until the handle is
+ * destroyed or another call replaces it.  The pointer is LATCHED: running episodes keep the
+ * speeds they started with; the next abr_env_reset picks the new ones up, and that reset must
+ * cover all lanes (lane_mask_dev == NULL, else ABR_E_INVALID).  NULL restores the single speed.
+ * Event-driven kernels only. */
+int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);   /* latched: see above */
 
 /* Which kernels serve reset/step: 0 (default) = event-driven, exact closed-form
  * stepping of the float64 tick sequences; 1 = one loop trip per 0.01 s tick.  Both
@@ -141,6 +146,10 @@ int abr_env_set_impl(abr_env *env, int32_t impl);
  * bandwidths[idx] is trace[(start_offset_dev[i] + idx) % len] (D7: wrap is
  * build-defined).  lane_mask_dev (nullable): only lanes with a non-zero byte
  * are reset.  obs_out_dev: float32 [ABR_OBS_DIM][n_lanes] (nullable).
+ * A lane whose trace id is outside [0, n_traces) or whose start offset is negative is
+ * frozen with ABR_DONE_BADARG (the reference would raise IndexError at Simulator.py:159).
+ * Every reset of a lane after its first starts the next episode number of the built-in
+ * counter-based policy (abr_env_step_random), so repeated episodes draw fresh actions.
  */
 int abr_env_reset(abr_env *env, const int32_t *trace_id_dev, const int32_t *start_offset_dev,
                   const uint8_t *lane_mask_dev, float *obs_out_dev, void *stream);
@@ -225,9 +234,12 @@ typedef struct abr_mpc_config {
  *  flat arg-min index; best_J_out_dev (nullable) float64 [n_lanes];
  *  lane_mask_dev (nullable): lanes with a zero byte are skipped entirely
  *  (no history mutation, outputs untouched).
+ *  previous_bitrate indexes the ladder as Python does (mpc.py:132,148): -n_rates..-1 wrap to
+ *  the top (the env's "no previous chunk" value -1 means the highest rate).
  *  Lanes the reference would raise on report action -1 (flat -1, J NaN) and keep their
- *  history: an empty or zero history (ZeroDivisionError, mpc.py:88,90, D13) and, without
- *  clip_horizon, chunk + horizon > video_length (IndexError, mpc.py:126, D12).
+ *  history: an empty or zero history (ZeroDivisionError, mpc.py:88,90, D13), a
+ *  previous_bitrate outside [-n_rates, n_rates) (IndexError) and, without clip_horizon,
+ *  chunk + horizon > video_length (IndexError, mpc.py:126, D12).
  */
 int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
                    const int32_t *prev_bitrate_dev, const double *buffer_dev, double *hist_n_dev,

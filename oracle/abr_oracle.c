@@ -306,7 +306,9 @@ double oracle_mpc_objective(const oracle_mpc_cfg *c, const double *br, const dou
     const int H = c->horizon, B = c->n_rates;
     int R[17];
     double buffer_vector[16];
-    R[0] = prev_bitrate;
+    /* R = [previous_bitrate] + ... indexes bitrates[i] (mpc.py:132,148): a negative index
+     * counts from the end of the list, as in Python (-1 = the highest rate) */
+    R[0] = prev_bitrate < 0 ? prev_bitrate + B : prev_bitrate;
     for (int i = 0; i < H; i++) { R[i + 1] = R_arg[i]; buffer_vector[i] = 0.0; }
     buffer_vector[0] = buffer_level;
     double video_quality = 0, quality_variance = 0, rebuffer_time = 0, startup_delay = 0;

@@ -26,7 +26,7 @@ def load_golden(name):
 ENV_GOLDENS = ["env_bench_shape", "env_l1_ladder4", "env_bufferfull_i05", "env_starved_i03",
                "env_speed125", "env_const_policy", "env_l3_i07"]
 MPC_GOLDENS = ["mpc_b6h5_cbr", "mpc_b6h5_vbr", "mpc_b4h5_l1", "mpc_b6h3_smallbuf", "mpc_b3h2",
-               "mpc_b5h4"]
+               "mpc_b5h4", "mpc_b6h4_prevneg"]
 
 
 @pytest.fixture(scope="session")

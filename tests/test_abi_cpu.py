@@ -101,6 +101,16 @@ def test_workspace_bytes_and_validation(L):
         assert len(lib.abr_last_error()) > 0
     assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 0, C.byref(n)) == -1
     assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, interval=1e-9)), 64, C.byref(n)) == -4
+    # a tick bound under which no episode can finish is an error at create time, not 100 % timeouts
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, max_ticks=48 * 400)), 64, C.byref(n)) == -1
+    assert b"ABR_DONE_TIMEOUT" in lib.abr_last_error()
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, max_ticks=49 * 400)), 64, C.byref(n)) == 0
+    # the default bound is never silently capped below the live-stream minimum
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, video_length=65535, chunk_length=4.0)), 64,
+                                       C.byref(n)) == 0
+    assert n.value > 2 * 8 * 2 * 65536 * 400
+    assert lib.abr_env_workspace_bytes(C.byref(_cfg(L, video_length=65535, chunk_length=100.0)), 64,
+                                       C.byref(n)) == -4
     with pytest.raises(L.AbrError):
         L.check(lib.abr_env_workspace_bytes(C.byref(_cfg(L, n_rates=99)), 64, C.byref(n)))
 

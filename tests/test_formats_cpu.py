@@ -31,7 +31,14 @@ def test_mpd_file(tmp_path):
     assert mpd.video_length == 3 and mpd.chunk_length == 4 and mpd.max_buffer == 20
     assert [list(c.bitrates) for c in mpd.chunks] == lads
     assert list(mpd.chunks[1].sizes) == [b * 4 for b in lads[1]]
-    assert mpd.ladder() == lads[0]
+    # the lines differ: there is no single ladder, and asking for one is an error, not chunk 0's
+    assert not mpd.uniform() and mpd.bitrate_table() == lads
+    with pytest.raises(ValueError):
+        mpd.ladder()
+    A.save_mpd_file(p, [lads[0]] * 3)
+    same = A.load_mpd_file(4, 20, 8, p)
+    assert same.uniform() and same.ladder() == lads[0]
+    assert A.MPD(3, 4, 20, 8, A.Chunk(lads[0])).ladder() == lads[0]
     open(p, "a").write("1 2\n")
     with pytest.raises(ValueError):
         A.load_mpd_file(4, 20, 8, p)

@@ -62,8 +62,10 @@ def _worker(rank, world, port, out):
     po = np.zeros((V, 3, nmax), np.float32); po[..., :n] = obs
     pr = np.zeros((V, nmax), np.float32); pr[..., :n] = rew
     g = ObsRewardGather((V, 3, nmax), (V, nmax), "cpu")
-    go, gr = g.gather(0, torch.from_numpy(po), torch.from_numpy(pr))
+    send = torch.cat([torch.from_numpy(po).reshape(-1), torch.from_numpy(pr).reshape(-1)])
+    go, gr = g.gather(0, send)                      # ONE collective for (obs, reward)
     g.finish()
+    assert g.n_collectives == 1
     full_o = unshard_lanes(go, counts).numpy()
     full_r = unshard_lanes(gr, counts).numpy()
     if rank == 0:
@@ -102,8 +104,11 @@ def test_xcd_aware_lane_assignment():
     w = np.arange(65536) // 64
     assert ((tid % 8) == (w % 8)).all()                 # workgroup w reads its XCD group's traces only
     assert len(np.unique(tid)) == 1024                  # every trace is still used
-    # a shard of a larger job keeps the property relative to its own workgroups
-    tid2, _ = lane_assignment(131072, 4096, lens, xcd_groups=8)
+    # a shard of a larger job reproduces the unsharded map (global lane ids) ...
+    tid2, off2 = lane_assignment(131072, 4096, lens, xcd_groups=8)
+    tidf, offf = lane_assignment(0, 262144, lens, xcd_groups=8)
+    assert (tid2 == tidf[131072:131072 + 4096]).all() and (off2 == offf[131072:131072 + 4096]).all()
+    # ... and keeps the XCD property relative to its own workgroups when lane0 % 512 == 0
     assert ((tid2 % 8) == ((np.arange(4096) // 64) % 8)).all()
     # falls back to i % n_traces when the table does not split evenly
     tid3, _ = lane_assignment(0, 100, [10] * 7, xcd_groups=8)

@@ -300,7 +300,7 @@ def _suminv(vals):
     return float(s)
 
 
-def gen_mpc(mpc):
+def gen_mpc(mpc, a_only=""):
     # ---- known answer: the mpc_test.py fixture (mpc_test.py:52-72) ----
     br4 = [1, 2.5, 5, 8]
     ka = mpc_case(mpc, [br4] * 60, [br4] * 60, 1, 20, 1, 0, 0, 20, 1, [2, 2.5, 4, 6, 8], 20, 5, True)
@@ -327,8 +327,16 @@ def gen_mpc(mpc):
         ("mpc_b6h3_smallbuf", ladder6, 3, 2, 5, (4.3, 1, 0.5), 24, True, 64, 4),
         ("mpc_b3h2", [1, 2, 4], 2, 2, 10, (2, 1, 0), 10, False, 16, 16),  # H=1 crashes the reference (mpc.py:186 indexes a scalar)
         ("mpc_b5h4", [0.5, 1, 2, 3, 5], 4, 2, 12, (3, 0.5, 0), 30, True, 48, 4),
+        # previous_bitrate < 0 ("no previous chunk" = -1 in the env): Python's negative index
+        # picks from the top of the ladder (mpc.py:148) -- drawn from a separate RNG stream so
+        # the older fixtures stay byte-identical
+        ("mpc_b6h4_prevneg", ladder6, 4, 4, 20, (4.3, 1, 0), 20, True, 32, 2),
     ]
     for name, lad, H, L, mb, (wr, wv, ws), V, vbr, n, nfull in sweeps:
+        if a_only and name != a_only:
+            continue        # only sweeps with an RNG stream of their own can be regenerated alone
+        if name.endswith("prevneg"):
+            rng = random.Random(777)
         B = len(lad)
         if vbr:
             br = [[b * rng.uniform(0.8, 1.2) for b in lad] for _ in range(V)]
@@ -341,6 +349,8 @@ def gen_mpc(mpc):
         for c in range(n):
             chunk = rng.randrange(0, V - H + 1)
             prev = rng.randrange(B)
+            if name.endswith("prevneg"):
+                prev = -1 if c % 2 == 0 else -rng.randrange(1, B + 1)
             buf = rng.choice([0.0, rng.uniform(0, mb), rng.uniform(0, mb), float(mb)])
             hl = rng.randrange(1, 12)
             hist = [rng.uniform(0.2, 6.0) for _ in range(hl)]
@@ -380,8 +390,8 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    if a.only in ("", "mpc"):
-        gen_mpc(load_mpc())
+    if a.only in ("", "mpc") or a.only.startswith("mpc_"):
+        gen_mpc(load_mpc(), a.only if a.only.startswith("mpc_") else "")
     if a.only in ("", "env"):
         S = load_simulator_repaired()
         for name, cfg in ENV_CONFIGS.items():
