@@ -124,6 +124,9 @@ int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t
 // Straight-line selects on purpose: this is the body of the GPU hot loop.
 template <int STOP>
 ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit_out) {
+#ifdef ABR_SEGMENT_HOOK
+    ABR_SEGMENT_HOOK(STOP);              // host-side analysis builds count segments per chain kind
+#endif
     double x = cs.x;
     int32_t inb = cs.inb, a = 0;
     const int e = expo(x);
@@ -193,6 +196,9 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
     a += go ? 1 : 0;
     cs.x = x; cs.inb = inb;
     hit_out = hit;
+#ifdef ABR_SEGMENT_END_HOOK
+    ABR_SEGMENT_END_HOOK(STOP, a, n, hit, (!go) | same);
+#endif
     return a;
 }
 

@@ -381,4 +381,73 @@ int oracle_mpc_select(const oracle_mpc_cfg *c, const double *br, const double *s
     return 0;
 }
 
+/* ------------------------------------------------------------------------
+ * Composition: Simulator.run() driven by MPCBitrateController.next_bitrate()
+ * ----------------------------------------------------------------------
+ * The reference does not wire the two (D5/D6); the evident wiring is
+ * chunk_info.previous_bandwidths = the simulator's own previous_bandwidths list
+ * (Simulator.py:155 passes it, mpc.py:168 reads it), so the predictor's appended
+ * predictions (mpc.py:92, D9) stay in the list the simulator keeps appending measured
+ * throughputs to (Simulator.py:164).  The harmonic mean runs over that whole list in
+ * order; carried here as (n, S = sum of 1/x in list order).
+ * Build-defined edges, as in include/abr_env.h: an empty history (chunk 0; the reference
+ * divides by zero, D13) takes bitrate 0 and leaves the history alone; near the video end
+ * the horizon is clipped to V - chunk (D12; the reference raises IndexError). */
+typedef struct {
+    const oracle_mpc_cfg *m;
+    const double *br, *sz;
+    double n, S;
+    int32_t seen;
+} oracle_mpc_policy_ctx;
+
+static int32_t oracle_mpc_policy(void *vctx, const oracle_step_rec *obs, const double *prev_bw,
+                                 int32_t n_prev)
+{
+    oracle_mpc_policy_ctx *c = (oracle_mpc_policy_ctx *)vctx;
+    for (int32_t i = c->seen; i < n_prev; i++) {          /* Simulator.py:164 appended these */
+        c->S = c->S + 1 / prev_bw[i];
+        c->n = c->n + 1;
+    }
+    c->seen = n_prev;
+    if (!(c->n > 0)) return 0;                            /* D13 */
+    const int H = c->m->horizon, V = c->m->video_length;
+    double pred[16];
+    oracle_mpc_predict_ns(H, &c->n, &c->S, pred);         /* D9: the list grows by H */
+    oracle_mpc_cfg m = *c->m;
+    int he = H;
+    if (obs->chunk_id + H > V) he = V - obs->chunk_id;    /* D12 clip */
+    m.horizon = he;
+    int64_t lead = 1;
+    for (int i = 1; i < he; i++) lead *= m.n_rates;
+    int64_t f = oracle_mpc_brute(&m, c->br, c->sz, obs->chunk_id, obs->last_bitrate,
+                                 obs->buffer_level, pred, NULL, NULL);
+    return (int32_t)(f / lead);
+}
+
+/* n_lanes episodes of the composition.  act_out: [n_lanes][V] chosen bitrates. */
+int64_t oracle_env_batch_mpc(const oracle_env_cfg *c, const oracle_mpc_cfg *m, const double *br,
+                             const double *sz, const double *traces, const int64_t *trace_off,
+                             const int32_t *trace_len, const int32_t *trace_id,
+                             const int32_t *offset, int32_t n_lanes, oracle_step_rec *steps,
+                             double *bw_out, int32_t *act_out, oracle_final_rec *fin,
+                             int64_t max_ticks)
+{
+    const int V = c->video_length;
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_lanes; i++) {
+        oracle_mpc_policy_ctx ctx = { m, br, sz, 0.0, 0.0, 0 };
+        oracle_final_rec f;
+        int t = trace_id[i];
+        int rc = oracle_env_episode(c, traces + trace_off[t], trace_len[t], offset[i], NULL,
+                                    oracle_mpc_policy, &ctx,
+                                    steps ? steps + (size_t)i * V : NULL,
+                                    bw_out ? bw_out + (size_t)i * V : NULL,
+                                    act_out ? act_out + (size_t)i * V : NULL, &f, max_ticks);
+        if (rc) return rc;
+        if (fin) fin[i] = f;
+        total += f.ticks;
+    }
+    return total;
+}
+
 int oracle_abi_version(void) { return 1; }

@@ -58,6 +58,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.oracle_env_batch.restype = C.c_int64
         _LIB.oracle_env_batch_speeds.restype = C.c_int64
+        _LIB.oracle_env_batch_mpc.restype = C.c_int64
         _LIB.oracle_mpc_brute.restype = C.c_int64
         _LIB.oracle_mpc_objective.restype = C.c_double
         assert STEP_DTYPE.itemsize == 96 and FINAL_DTYPE.itemsize == 72
@@ -122,6 +123,45 @@ def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=
     if rc < 0:
         raise RuntimeError(f"oracle_env_batch failed: {rc}")
     return steps, bw, fin, int(rc)
+
+
+def env_batch_mpc(cfg, mcfg, br, sz, traces, trace_id, offset, max_ticks=1 << 40, threads=1):
+    """Episodes of Simulator.run() driven by the MPC (see abr_oracle.c: composition).
+    Returns (steps[N,V], bw[N,V], actions[N,V], final[N]).  threads > 1 splits the lanes
+    over a thread pool (ctypes releases the GIL)."""
+    flat, off, lens = pack_traces(traces)
+    br = np.ascontiguousarray(br, np.float64)
+    sz = np.ascontiguousarray(sz, np.float64)
+    trace_id = np.ascontiguousarray(trace_id, np.int32)
+    offset = np.ascontiguousarray(offset, np.int32)
+    N, V = len(trace_id), cfg.video_length
+    steps = np.zeros((N, V), STEP_DTYPE)
+    bw = np.zeros((N, V), np.float64)
+    acts = np.zeros((N, V), np.int32)
+    fin = np.zeros(N, FINAL_DTYPE)
+    L = lib()
+
+    def run(lo, hi):
+        if hi <= lo:
+            return 0
+        rc = L.oracle_env_batch_mpc(
+            C.byref(cfg), C.byref(mcfg), _p(br, C.c_double), _p(sz, C.c_double),
+            _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
+            _p(trace_id[lo:hi], C.c_int32), _p(offset[lo:hi], C.c_int32), C.c_int32(hi - lo),
+            steps[lo:hi].ctypes.data_as(C.c_void_p), _p(bw[lo:hi], C.c_double),
+            _p(acts[lo:hi], C.c_int32), fin[lo:hi].ctypes.data_as(C.c_void_p), C.c_int64(max_ticks))
+        if rc < 0:
+            raise RuntimeError(f"oracle_env_batch_mpc failed: {rc}")
+        return rc
+
+    if threads <= 1:
+        run(0, N)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = np.linspace(0, N, threads + 1).astype(int)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: run(cuts[i], cuts[i + 1]), range(threads)))
+    return steps, bw, acts, fin
 
 
 POLICY_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32)

@@ -1,0 +1,284 @@
+"""Every BASELINE.json configuration that fits one GPU, through the C ABI, against the oracle.
+
+  configs[2]  K3 at 65 536 lanes, 6 rates, horizon 5, per-chunk (VBR) tables
+  configs[3]  the per-rank shape of the 8-GPU job: 131 072 lanes with lane_id_base = r * 131072,
+              r in {0, 7}, equal to the matching slice of the unsharded 1 048 576-lane run and to
+              an oracle replay of sampled lanes
+  configs[4]  mixed trace lengths 300-3 000 (wrap-around) x MPC-driven rollout, full 48-chunk
+              episodes, against the oracle composition (oracle/abr_oracle.c: oracle_env_batch_mpc)
+  N > 1       two fresh child processes, one HIP env shard each, gathered with the product's one
+              collective (gloo here; RCCL needs two GPUs) == the unsharded HIP run
+plus the ABI edges hardened in round 2 (reset range checks, latched lane speeds, episode
+counter, previous_bitrate range).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import make_env, philox_action
+
+pytestmark = pytest.mark.gpu
+
+LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
+V, L, MAX_BUFFER, START_UP = 48, 4.0, 20.0, 8.0
+WEIGHTS = [4.3, 1, 1, 0.1]
+META = dict(ladder=LADDER, chunk_length=L, video_length=V, max_buffer=MAX_BUFFER,
+            start_up_length=START_UP, interval=1.0, weights=WEIGHTS, speed=1.0)
+
+
+def _traces(n=1024, mixed=False, seed=0):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(300, 3001, n) if mixed else np.full(n, 1000)
+    return [rng.uniform(0.2, 6.0, int(m)).astype(np.float32).astype(np.float64) for m in lens]
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[2]: K3 at full size
+# ---------------------------------------------------------------------------------------------
+def test_mpc_65536_lanes_vbr_against_oracle(oracle):
+    from test_mpc_gpu import _controller
+    N, B, H = 65536, 6, 5
+    rng = np.random.default_rng(2026)
+    br = np.array(LADDER)[None, :] * rng.uniform(0.8, 1.2, (V, B))
+    sz = br * L * rng.uniform(0.7, 1.3, (V, B))
+    chunk = rng.integers(0, V - H + 1, N).astype(np.int32)
+    prev = rng.integers(0, B, N).astype(np.int32)
+    buf = np.where(rng.random(N) < 0.15, 0.0, rng.uniform(0, MAX_BUFFER, N))
+    buf[rng.random(N) < 0.05] = MAX_BUFFER
+    hn = rng.integers(1, 48, N).astype(np.float64)
+    hs = hn / rng.uniform(0.2, 6.0, N)
+    ctl, ci = _controller(br, sz, L, MAX_BUFFER, 4.3, 1.0, 0.0, H, chunk, prev, buf, hn, hs)
+    a = ctl.next_bitrate(want_details=True).cpu().numpy()
+    flat, J = ctl.last_flat.cpu().numpy(), ctl.last_J.cpu().numpy()
+    assert a.min() >= 0 and a.max() < B and np.isfinite(J).all()
+    # size-independent property on EVERY lane: the action is the leading digit of the arg-min
+    assert np.array_equal(a, flat // B ** (H - 1))
+    assert np.array_equal(ci.hist_n.cpu().numpy(), hn + H)                  # D9 everywhere
+    # exact oracle replay of >= 2 048 sampled lanes incl. the first and last workgroups (7 lanes each)
+    pick = np.unique(np.concatenate([np.arange(14), np.arange(N - 14, N), rng.integers(0, N, 2100)]))
+    assert len(pick) >= 2048
+    cfg = oracle.mpc_cfg(B, H, V, L, MAX_BUFFER, 1.0, 4.3, 0.0)
+    hn_o, hs_o = hn[pick].copy(), hs[pick].copy()
+    act, fl, Jm, _ = oracle.mpc_select(cfg, br, sz, chunk[pick], prev[pick], buf[pick], hn_o, hs_o)
+    assert np.array_equal(a[pick], act)
+    assert np.array_equal(flat[pick].astype(np.int64), fl)
+    assert np.array_equal(J[pick], Jm)
+    assert np.array_equal(ci.hist_sum_inv.cpu().numpy()[pick], hs_o)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[3]: per-rank shard shape of the 1 048 576-lane job
+# ---------------------------------------------------------------------------------------------
+def test_shard_shape_131072_lanes_equals_unsharded_slice_and_oracle(oracle):
+    from abrsimulator_amd.sharding import lane_assignment, shard_range
+    TOTAL, WORLD, SEED = 1048576, 8, 20260404
+    traces = _traces()
+    lens = [len(t) for t in traces]
+    full = make_env(META, traces, TOTAL, auto_reset=True)
+    tid, off = lane_assignment(0, TOTAL, lens)
+    full.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    ref = full.step_random(V, SEED)
+    assert int(ref["done"][-1].sum()) == TOTAL and int(ref["done"][:-1].sum()) == 0
+    for r in (0, 7):
+        lane0, n = shard_range(TOTAL, WORLD, r)
+        assert (lane0, n) == (r * 131072, 131072)
+        stid, soff = lane_assignment(lane0, n, lens)
+        assert np.array_equal(stid, tid[lane0:lane0 + n]) and np.array_equal(soff, off[lane0:lane0 + n])
+        sh = make_env(META, traces, n, auto_reset=True, lane_id_base=lane0)
+        sh.reset(torch.from_numpy(stid), torch.from_numpy(soff))
+        out = sh.step_random(V, SEED)
+        for k in ("obs", "reward", "done", "actions"):
+            assert torch.equal(out[k], ref[k][..., lane0:lane0 + n]), (r, k)
+        if r != 7:
+            continue
+        # oracle replay of sampled lanes of the LAST shard (global lane ids in the philox counter)
+        rng = np.random.default_rng(7)
+        pick = np.unique(np.concatenate([[0, 63, 64, n - 64, n - 1], rng.integers(0, n, 1024)]))
+        want = np.stack([philox_action(SEED, lane0 + pick, s, 0, 6) for s in range(V)], 1)
+        acts = out["actions"].cpu().numpy()[:, pick].T
+        assert np.array_equal(acts, want)
+        cfg = oracle.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
+        steps, bw, fin, _ = oracle.env_batch(cfg, traces, stid[pick], soff[pick], acts.copy())
+        o = out["obs"].cpu().numpy()[:, :, pick]
+        for s in range(V - 1):
+            assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), s
+            assert np.array_equal(o[s, 4], steps["global_time"][:, s + 1].astype(np.float32)), s
+            assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32)), s
+        # the finished episode (auto_reset keeps its record): float64 QoE against the oracle
+        assert np.allclose(sh.episode_qoe().cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[4]: mixed trace lengths x MPC-driven rollout
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wv,wr", [(1.0, 4.3), (0.5, 0.3)])     # the bench weights; a mix of all six rates
+def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr):
+    import abrsimulator_amd as A
+    from abrsimulator_amd.sharding import lane_assignment
+    N, H = 512, 5
+    traces = _traces(64, mixed=True, seed=4)
+    lens = [len(t) for t in traces]
+    assert min(lens) < 500 and max(lens) > 2500
+    tid, off = lane_assignment(0, N, lens)
+    rng = np.random.default_rng(44)
+    br = np.array(LADDER)[None, :] * rng.uniform(0.8, 1.2, (V, 6))      # VBR: per-chunk tables
+    sz = br * L * rng.uniform(0.7, 1.3, (V, 6))
+    # the env itself downloads CBR chunks (one ladder, Simulator.py:156); the MPC plans on
+    # the per-chunk tables (mpc.py:126-128) -- exactly the split the reference has
+    env = make_env(META, traces, N)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    mpd = A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(list(b), list(s)) for b, s in zip(br, sz)])
+    player = A.EnvPlayer(env, mpd=mpd, qoe=A.QOEMetric(wr, wv, 0.0))
+    ctl = A.BatchedMPCController(player, horizon=H, clip_horizon=True)
+    gpu_actions = []
+    for s in range(V):
+        a = torch.clamp(ctl.next_bitrate(), min=0)          # D13 at chunk 0: "no decision" -> rate 0
+        gpu_actions.append(a.cpu().numpy().copy())
+        env.step(a)
+    gpu_actions = np.stack(gpu_actions, 1)
+    ecfg = oracle.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
+    mcfg = oracle.mpc_cfg(6, H, V, L, MAX_BUFFER, wv, wr, 0.0)
+    steps, bw, acts, fin = oracle.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid, off, threads=8)
+    assert np.array_equal(gpu_actions, acts)
+    if wr < 1.0:
+        assert len(np.unique(acts)) == 6                     # every rate is exercised
+    # some lanes wrapped around their trace (the reference would raise IndexError, D7)
+    assert (fin["global_time"] > np.array(lens)[tid] - off).any()
+    assert np.array_equal(env.history()[1].cpu().numpy().T, bw)
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    f = env.observe_f64()
+    for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
+        assert np.array_equal(f[k].cpu().numpy(), fin[k]), k
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1: two ranks, HIP shards, the product's collective
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_hip_shards_gather_equals_unsharded_hip_run(tmp_path):
+    from abrsimulator_amd.sharding import lane_assignment
+    TOTAL, WORLD, VV, SEED = 4096 + 64, 2, 12, 99
+    traces = _traces(16, seed=9)
+    meta = dict(META, video_length=VV)
+    env = make_env(meta, traces, TOTAL, auto_reset=True)
+    tid, off = lane_assignment(0, TOTAL, [len(t) for t in traces])
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    ref = env.step_random(VV, SEED)
+    out = str(tmp_path / "gathered.npz")
+    port = _free_port()
+    procs = []
+    for r in range(WORLD):
+        e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
+                 WORLD_SIZE=str(WORLD), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"),
+                                       str(TOTAL), str(VV), str(SEED), out], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    g = np.load(out)
+    assert int(g["n_collectives"]) == 1                      # ONE all-gather for (obs, reward)
+    assert np.array_equal(g["obs"], ref["obs"][VV - 1].cpu().numpy())
+    assert np.array_equal(g["reward"], ref["reward"].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# ABI edges
+# ---------------------------------------------------------------------------------------------
+def test_reset_with_bad_trace_id_or_offset_freezes_the_lane():
+    import abrsimulator_amd as A
+    from abrsimulator_amd import _lib
+    traces = _traces(4, seed=1)
+    env = make_env(dict(META, video_length=4), traces, 128)
+    tid = (torch.arange(128, dtype=torch.int32) % 4).cuda()
+    off = torch.zeros(128, dtype=torch.int32).cuda()
+    tid[3] = 4; tid[9] = -1; off[17] = -5                    # through the C ABI, past env.reset's checks
+    _lib.check(env.lib.abr_env_reset(env._h, _lib.ptr(tid), _lib.ptr(off), None, _lib.ptr(env.obs),
+                                     _lib.current_stream(env.device)))
+    a = torch.zeros(128, dtype=torch.int32).cuda()
+    _, _, done = env.step(a)
+    d = done.cpu().numpy()
+    assert (d[[3, 9, 17]] == _lib.DONE_BADARG).all() and (np.delete(d, [3, 9, 17]) == 0).all()
+    with pytest.raises(ValueError):
+        env.reset(tid.cpu(), off.cpu())                      # the Python front end refuses outright
+
+
+def test_lane_speeds_are_latched_until_a_full_reset(oracle):
+    from abrsimulator_amd import _lib
+    rng = np.random.default_rng(3)
+    traces = _traces(4, seed=2)
+    VV, N = 6, 256
+    meta = dict(META, video_length=VV)
+    tid = rng.integers(0, 4, N).astype(np.int32); off = rng.integers(0, 1000, N).astype(np.int32)
+    actions = rng.integers(0, 6, (N, VV)).astype(np.int32)
+    acts = torch.from_numpy(actions).cuda()
+    cfg = oracle.env_cfg(LADDER, L, VV, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
+    env = make_env(meta, traces, N)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    env.step(acts[:, 0].contiguous())
+    speeds = torch.from_numpy(rng.choice([0.8, 1.0, 1.25], N)).cuda()
+    _lib.check(env.lib.abr_env_set_lane_speeds(env._h, _lib.ptr(speeds)))
+    # mid-episode: the running episodes keep speed 1.0 (bit-exact against the oracle at speed 1)
+    for s in range(1, VV):
+        env.step(acts[:, s].contiguous())
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, actions)
+    assert np.array_equal(env.observe_f64()["buffer_level"].cpu().numpy(), fin["buffer_level"])
+    assert np.array_equal(env.history()[1].cpu().numpy().T, bw)
+    # a masked reset cannot adopt new speeds
+    mask = torch.zeros(N, dtype=torch.uint8); mask[0] = 1
+    with pytest.raises(_lib.AbrError):
+        env.reset(torch.from_numpy(tid), torch.from_numpy(off), mask=mask)
+    # the next full reset does
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    for s in range(VV):
+        env.step(acts[:, s].contiguous())
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, actions, speeds=speeds.cpu().numpy())
+    assert np.array_equal(env.observe_f64()["play_time"].cpu().numpy(), fin["play_time"])
+    assert np.array_equal(env.observe_f64()["buffer_level"].cpu().numpy(), fin["buffer_level"])
+
+
+def test_every_reset_starts_a_new_policy_episode():
+    traces = _traces(4, seed=5)
+    VV, N, SEED = 5, 192, 31337
+    env = make_env(dict(META, video_length=VV), traces, N)
+    env.reset()
+    a0 = env.step_random(VV, SEED)["actions"].cpu().numpy()
+    assert np.array_equal(a0, np.stack([philox_action(SEED, np.arange(N), s, 0, 6) for s in range(VV)]))
+    mask = torch.zeros(N, dtype=torch.uint8); mask[:64] = 1
+    env.reset(mask=mask)                                      # lanes 0..63 start episode 1
+    a1 = env.step_random(VV, SEED)["actions"].cpu().numpy()
+    want = np.stack([philox_action(SEED, np.arange(64), s, 1, 6) for s in range(VV)])
+    assert np.array_equal(a1[:, :64], want)
+    assert (a1[:, 64:] == -1).all()                           # finished lanes stay finished
+    env.reset()                                               # everyone: episodes 2 and 1
+    a2 = env.step_random(VV, SEED)["actions"].cpu().numpy()
+    assert np.array_equal(a2[:, :64], np.stack([philox_action(SEED, np.arange(64), s, 2, 6) for s in range(VV)]))
+    assert np.array_equal(a2[:, 64:], np.stack([philox_action(SEED, np.arange(64, N), s, 1, 6) for s in range(VV)]))
+
+
+def test_mpc_previous_bitrate_outside_the_ladder_is_no_decision():
+    from test_mpc_gpu import _controller
+    B, H, VV = 6, 5, 20
+    br = np.tile(np.array(LADDER), (VV, 1)); sz = br * L
+    prev = np.array([-7, -6, -1, 0, 5, 6, 100], np.int32)
+    n = len(prev)
+    ctl, ci = _controller(br, sz, L, MAX_BUFFER, 4.3, 1.0, 0.0, H, np.full(n, 3, np.int32), prev,
+                          np.full(n, 5.0), np.full(n, 4.0), np.full(n, 2.0))
+    a = ctl.next_bitrate(want_details=True).cpu().numpy()
+    assert (a[[0, 5, 6]] == -1).all() and (a[1:5] >= 0).all()
+    hn = ci.hist_n.cpu().numpy()
+    assert (hn[[0, 5, 6]] == 4.0).all() and (hn[1:5] == 9.0).all()
+    # Python's negative index: -6 is rate 0, -1 is rate 5
+    assert float(ctl.last_J[1]) == float(ctl.last_J[3]) and float(ctl.last_J[2]) == float(ctl.last_J[4])
