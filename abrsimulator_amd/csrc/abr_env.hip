@@ -486,7 +486,7 @@ __device__ inline abrx::Tables make_tables(const EnvParams &p) {
 __device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
     s.buf = p.buf[i]; s.sumk = p.sumk[i];
     s.k = p.k[i]; s.chunk_id = p.chunk_id[i]; s.n_su = p.n_su[i]; s.n_rb = p.n_rb[i];
-    s.n_play = p.n_play[i]; s.j = p.j[i]; s.tpos = p.tpos[i];
+    s.n_play = p.n_play[i]; s.cur.j = p.j[i]; s.cur.tpos = p.tpos[i];
     s.last_action = p.last_action[i];
     const uint8_t f = p.flags[i];
     s.su = f & kFlagStartUp; s.be = f & kFlagBufEmpty; s.bf = f & kFlagBufFull;
@@ -498,7 +498,7 @@ __device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
 __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i) {
     p.buf[i] = s.buf; p.sumk[i] = s.sumk;
     p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
-    p.n_play[i] = s.n_play; p.j[i] = s.j; p.tpos[i] = s.tpos; p.last_action[i] = s.last_action;
+    p.n_play[i] = s.n_play; p.j[i] = s.cur.j; p.tpos[i] = s.cur.tpos; p.last_action[i] = s.last_action;
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
                            (s.bf ? kFlagBufFull : 0) | kFlagArmed);
     if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                 // a re-armed lane starts a NEW episode of the counter-based policy
                 episode_no = (p.flags[i] & kFlagArmed) ? p.episode_no[i] + 1 : 0;
                 p.trace_id[i] = t; p.offset0[i] = offset0;
-                s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+                s.cur.tlen = p.trace_len[t]; s.cur.trace = p.traces + p.trace_off[t];
                 s.sd = p.lane_speeds ? p.lane_speeds[i] * kDt : p.sd;     // play_speed * dt (:182)
                 abrx::lanej_init(s, tb, offset0);
                 if (!bad && !abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
             done = p.done[i];
             const int32_t t = p.trace_id[i];
             offset0 = p.offset0[i];
-            s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
+            s.cur.tlen = p.trace_len[t]; s.cur.trace = p.traces + p.trace_off[t];
             lanej_load(s, p, i);
             n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
             last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
             if (active) {
                 // one burst of loads for everything the step needs (issued before the
                 // policy arithmetic so that the two overlap)
-                const abrx::StepStart st = abrx::lanej_begin_step(s, tb);
+                const abrx::StepStart st = abrx::lanej_begin_step(s.cur, tb, s.k, s.chunk_id);
                 // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
                 int32_t a;
                 if (MODE == 1) a = actions[i];

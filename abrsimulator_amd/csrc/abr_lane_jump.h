@@ -44,25 +44,42 @@ struct Tables {
     bool per_lane_speed;           // each lane carries its own speed*dt and play_time (8f rank 3)
 };
 
+// Where a lane is in its bandwidth trace.  Only the download side (phase A) reads it.
+struct Cursor {
+    int32_t j;                     // interval index of the clock, int(global_time / interval) (:158)
+    int32_t tpos;                  // (offset0 + j) mod tlen: bandwidths[idx] of that interval (:159)
+    int32_t tlen;
+    const double *trace;
+};
+
 struct LaneJ {
     double buf;                    // buffer_level
     double sd;                     // this lane's speed*dt (== Tables::sd unless per_lane_speed)
     double pt;                     // play_time, carried only when per_lane_speed (else GP[n_play])
     long long sumk;                // sum of tick indices of playing ticks (latency integral)
-    int32_t k, chunk_id, n_su, n_rb, n_play, j, tpos, tlen, avail_k, last_action;
+    int32_t k, chunk_id, n_su, n_rb, n_play, avail_k, last_action;
     bool su, be, bf;               // start_up, buffer_empty, buffer_full
-    const double *trace;
+    Cursor cur;
 };
 
-ABR_HD void lanej_init(LaneJ &s, const Tables &t, int32_t offset0) {
-    // Simulator.py:95-130, then T1-T3 of tick 0 (start_up_time += dt)
+ABR_HD void cursor_init(Cursor &c, int32_t offset0) {
+    c.j = 0;                       // int(0.0 / interval)
+    c.tpos = offset0 % c.tlen;
+}
+
+// Simulator.py:95-130, then T1-T3 of tick 0 (start_up_time += dt); everything but the cursor
+ABR_HD void lanej_init_player(LaneJ &s, const Tables &t) {
     s.buf = 0.0; s.sumk = 0;
     s.k = 0; s.chunk_id = 0; s.n_su = 1; s.n_rb = 0; s.n_play = 0;
     s.last_action = -1;
     s.su = true; s.be = true; s.bf = false;
-    s.j = 0; s.tpos = offset0 % s.tlen;
     s.avail_k = t.avail_tick[0];
     s.pt = 0.0;                    // play_time = 0 (:115); s.sd is set by the caller
+}
+
+ABR_HD void lanej_init(LaneJ &s, const Tables &t, int32_t offset0) {
+    lanej_init_player(s, t);
+    cursor_init(s.cur, offset0);
 }
 
 // play_time += speed*dt for `a` playing ticks (:182).  With one speed for all lanes
@@ -164,7 +181,7 @@ ABR_HD int32_t trace_wrap(int32_t pos, int32_t tlen) {
     return pos;
 }
 
-ABR_HD StepStart lanej_begin_step(LaneJ &s, const Tables &t) {
+ABR_HD StepStart lanej_begin_step(Cursor &s, const Tables &t, int32_t k, int32_t chunk_id) {
     int32_t ke[kCatch + 2];
     double bw[kCatch + 2];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -175,18 +192,18 @@ ABR_HD StepStart lanej_begin_step(LaneJ &s, const Tables &t) {
         bw[i] = s.trace[trace_wrap(s.tpos + i, s.tlen)];
     }
     StepStart st;
-    st.avail_next = t.avail_tick[s.chunk_id + 1];
+    st.avail_next = t.avail_tick[chunk_id + 1];
     // intervals the cursor is behind: ke[] is non-decreasing
     int32_t adv = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < kCatch; i++) adv += (s.k >= ke[i]) ? 1 : 0;
-    if (adv == kCatch && s.k >= ke[kCatch]) {
+    for (int i = 0; i < kCatch; i++) adv += (k >= ke[i]) ? 1 : 0;
+    if (adv == kCatch && k >= ke[kCatch]) {
         // more than kCatch intervals behind (a long buffer_full wait): walk, then reload
         s.j += kCatch; s.tpos = trace_wrap(s.tpos + kCatch, s.tlen);
         int32_t e = t.interval_tick[s.j + 1];
-        while (s.k >= e) {
+        while (k >= e) {
             s.j++;
             s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
             e = t.interval_tick[s.j + 1];
@@ -214,23 +231,27 @@ ABR_HD StepStart lanej_begin_step(LaneJ &s, const Tables &t) {
     return st;
 }
 
-// One decision, after lanej_begin_step: download a chunk of target_size, then run to the
-// next call site.  `action` only labels the step (last_action).
-ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepStart &st,
-                                          double target, int32_t action) {
-    StepResult r;
-    r.bw = 0.0; r.hit = false; r.ended = false; r.timeout = false;
-    const int32_t mt = t.max_ticks;
-    // ---- phase A: downloaded_size over the trace intervals ----
+// Phase A of one decision: the download side.  Needs nothing of the player state but
+// the call-site tick k: the download cannot pause before it completes, so it is a pure
+// function of (k, cursor, target) -- which is what lets a second thread run the player
+// side of the SAME lane concurrently (abr_env.hip: env_split_kernel).
+struct Download {
+    double dl;        // downloaded_size at the completing tick (:160-163)
+    int32_t n_dl;     // ticks it took: download_time = G[n_dl] (:161)
+    bool hit;         // false: max_ticks reached first
+};
+
+ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, int32_t k,
+                               double target) {
     // One flat loop over chain SEGMENTS (abr_exact_jump.h); a lane moves on to its next
     // trace interval between two segments.  The next interval's bandwidth and end tick
     // are loaded one interval ahead so the loads overlap the arithmetic.
-    const int32_t lim = mt - s.k;
+    const int32_t lim = t.max_ticks - k;
     int32_t ke = st.ke, ke_next = st.ke_next, tn = st.tn;
     double c = st.c, bw_next = st.bw_next;
     ChainState cs;
     cs.x = 0.0; cs.d = 0.0; cs.inb = 0;       // downloaded_size = 0 at a call site
-    int32_t n_dl = 0, kk = s.k;
+    int32_t n_dl = 0, kk = k;
     bool hit = false;
     {
         // Prologue: downloaded_size starts at 0, so its first additions cross a binade
@@ -266,7 +287,21 @@ ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepS
         const int32_t adds = chain_segment<STOP_GE>(cs, c, target, n, hit);       // :160-163
         n_dl += adds; kk += adds;
     }
-    const double dl = cs.x;
+    Download d;
+    d.dl = cs.x; d.n_dl = n_dl; d.hit = hit;
+    return d;
+}
+
+// The rest of the decision: the player side of the download's ticks, the completing tick,
+// then phase B up to the next call site.  `action` only labels the step (last_action);
+// avail_next = avail_tick[chunk_id + 1].
+ABR_HD StepResult lanej_after_download(LaneJ &s, const Tables &t, const Download &d,
+                                       int32_t avail_next, int32_t action) {
+    StepResult r;
+    r.bw = 0.0; r.hit = false; r.ended = false; r.timeout = false;
+    const int32_t mt = t.max_ticks;
+    const bool hit = d.hit;
+    const int32_t n_dl = d.n_dl;
     const double g_ndl = t.G[n_dl];           // download_time; loaded now, divided by much later
     // ---- buffer side of the ticks before the completing one ----
     lanej_idle(s, t, hit ? n_dl - 1 : n_dl);
@@ -282,10 +317,10 @@ ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepS
     s.su = s.su && !(b >= t.start_up_length);                                // :201-202
     s.k++;                                                                   // :205
     r.hit = true;
-    r.bw = dl / g_ndl;                                                       // :164
+    r.bw = d.dl / g_ndl;                                                     // :164
     s.last_action = action;
     s.chunk_id++;                                                            // :166
-    s.avail_k = st.avail_next;
+    s.avail_k = avail_next;
     r.ended = s.chunk_id >= t.V;                                             // :207-208
     r.timeout = !r.ended && s.k >= mt;
     if (!r.ended && !r.timeout) {
@@ -296,9 +331,17 @@ ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepS
     return r;
 }
 
+// One decision in one thread, after lanej_begin_step: download a chunk of target_size, then
+// run to the next call site.
+ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepStart &st,
+                                          double target, int32_t action) {
+    const Download d = lanej_download(s.cur, t, st, s.k, target);
+    return lanej_after_download(s, t, d, st.avail_next, action);
+}
+
 // begin + download + wait in one call (host harness)
 ABR_HD StepResult lanej_step(LaneJ &s, const Tables &t, double target, int32_t action) {
-    const StepStart st = lanej_begin_step(s, t);
+    const StepStart st = lanej_begin_step(s.cur, t, s.k, s.chunk_id);
     return lanej_download_and_wait(s, t, st, target, action);
 }
 

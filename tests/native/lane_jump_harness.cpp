@@ -41,7 +41,7 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
     Ctx *c = (Ctx *)h;
     abrx::Tables t = c->t;
     abrx::LaneJ s;
-    s.trace = trace; s.tlen = tlen;
+    s.cur.trace = trace; s.cur.tlen = tlen;
     s.sd = t.sd;
     if (lane_speed > 0.0) { t.per_lane_speed = true; s.sd = lane_speed * 0.01; }   // :182 product
     abrx::lanej_init(s, t, offset);
