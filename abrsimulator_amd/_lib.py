@@ -14,6 +14,8 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libabr_hip.so")
+if os.environ.get("ABR_HIP_LIB"):          # diagnostic builds of the same ABI (csrc/Makefile)
+    SO_PATH = os.path.join(CSRC, os.environ["ABR_HIP_LIB"])
 
 ABI_VERSION = 1
 MAX_RATES = 16

@@ -99,7 +99,8 @@ struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
-    int impl;   // 0 = event-driven kernels (default), 1 = tick-by-tick kernels (cross-check)
+    int impl;   // 2 = role-split event-driven kernels (default), 0 = one thread per lane,
+                // 1 = tick-by-tick kernels (cross-check)
     const double *pending_speeds;   // abr_env_set_lane_speeds: latched into p.lane_speeds by the next full reset
     bool speeds_dirty;
 };
@@ -653,6 +654,284 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1, role-split form (impl 2, the default for step / step_random)
+// ---------------------------------------------------------------------------
+// Measured on MI355X (profiles/r02_valu_cost_microbench.txt): ONE wave on a SIMD issues a
+// vector instruction every 4.1-4.5 cycles (float64: 5.4-6.4) however independent its
+// instructions are; two waves per SIMD get 2.1 (3.7), four 1.6 (2.8).  65 536 lanes are 1 024
+// waves = one per SIMD, so the one-thread-per-lane kernel above leaves more than half of every
+// SIMD's issue slots empty at the headline size.  A lane's step has two halves that do not
+// need each other's float64 state (abr_lane_jump.h):
+//   D  the download: a pure function of (call-site tick, trace cursor, target size)
+//   P  the player:   buffer_level / play_time / counters over the download's ticks, the
+//                    completing tick, phase B, then reward / observation / history
+// so a workgroup is TWO waves over the same 64 lanes: wave 0 runs D of step s+1 while wave 1
+// runs P of step s.  The only thing D needs from P is the next call-site tick, which is
+// max(completion tick + 1, avail_tick[chunk + 1]) unless buffer_full gates the download
+// (Simulator.py:144).  D therefore SPECULATES "not gated"; P publishes its true call-site
+// tick every iteration and accepts a download record only if it started at exactly that tick.
+// A mis-speculated lane repeats that one download with the right tick in the next iteration
+// (one extra trip for that lane; nothing is ever rolled back in P, which only consumes
+// validated records).  One workgroup barrier per iteration; both waves run the same number
+// of iterations, so the barrier count always matches.
+// Workspace layout and results are those of the kernels above, bit for bit.
+struct SplitMail {
+    // D -> P, double-buffered by iteration parity
+    double dl[2][64];
+    int32_t n_dl[2][64], k_start[2][64], step[2][64], action[2][64], avail_next[2][64], flags[2][64];
+    // P -> D, double-buffered by iteration parity
+    int32_t fb_step[2][64], fb_k[2][64], fb_chunk[2][64], fb_episode[2][64], fb_alive[2][64];
+    int32_t any_alive[2];
+};
+constexpr int kRecValid = 1, kRecHit = 2, kRecBadAct = 4;
+
+__device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, int64_t i) {
+    p.buf[i] = s.buf; p.sumk[i] = s.sumk;
+    p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
+    p.n_play[i] = s.n_play; p.last_action[i] = s.last_action;
+    p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
+                           (s.bf ? kFlagBufFull : 0) | kFlagArmed);
+    if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
+}
+
+#ifdef ABR_SPLIT_STAMPS
+#define SPLIT_STAMP_DECL long long st_work = 0, st_wait = 0, st_iters = 0;
+#define SPLIT_STAMP_T0 const long long st0 = __builtin_amdgcn_s_memtime();
+#define SPLIT_STAMP_T1 const long long st1 = __builtin_amdgcn_s_memtime();
+#define SPLIT_STAMP_T2 st_work += st1 - st0; st_wait += __builtin_amdgcn_s_memtime() - st1; st_iters++;
+// the unused 4th row of ep_qoe_terms: [work, wait, iterations] of D (slots 0-2) and P (slots 3-5)
+#define SPLIT_STAMP_OUT(base)                                                                       \
+    if (in_range && l < 3)                                                                           \
+        p.ep_qoe_terms[3 * p.n_lanes + (int64_t)blockIdx.x * 64 + l + (base)] =                      \
+            (double)(l == 0 ? st_work : (l == 1 ? st_wait : st_iters));
+#else
+#define SPLIT_STAMP_DECL
+#define SPLIT_STAMP_T0
+#define SPLIT_STAMP_T1
+#define SPLIT_STAMP_T2
+#define SPLIT_STAMP_OUT(base)
+#endif
+
+// Wave 0 of a workgroup: the download side of its 64 lanes.  Executes exactly one workgroup
+// barrier per iteration, as split_role_player does, and leaves the loop in the same iteration.
+template <int MODE>
+__device__ __forceinline__ void split_role_download(
+    const EnvParams &p, SplitMail &m, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, int32_t n_total, uint64_t seed) {
+    const int l = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 64 + l;
+    const bool in_range = i < p.n_lanes;
+    const int32_t V = p.video_length;
+    const abrx::Tables tb = make_tables(p);
+    abrx::Cursor cur; cur.j = 0; cur.tpos = 0; cur.tlen = 1; cur.trace = p.traces;
+    int32_t snap_j = 0, snap_tpos = 0;             // cursor before the download just issued
+    int32_t d_step = 0, d_k = 0, d_chunk = 0, d_ep = 0, offset0 = 0;
+    int32_t issued_step = -1, issued_k = -1;
+    bool d_alive = false, was_alive = false;
+    if (in_range) {
+        const int32_t t = p.trace_id[i];
+        offset0 = p.offset0[i];
+        cur.tlen = p.trace_len[t]; cur.trace = p.traces + p.trace_off[t];
+        cur.j = p.j[i]; cur.tpos = p.tpos[i];
+        d_k = p.k[i]; d_chunk = p.chunk_id[i]; d_ep = p.episode_no[i];
+        d_alive = was_alive = !p.done[i];
+    }
+    SPLIT_STAMP_DECL
+    for (int32_t t = 0;; t++) {
+        const int cb = t & 1;                      // this iteration's mailbox slot
+        SPLIT_STAMP_T0
+        // ---- download of step d_step, started at its (predicted) call site ----
+        int32_t flags = 0;
+        if (d_alive && d_step < n_total) {
+            snap_j = cur.j; snap_tpos = cur.tpos;
+            const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
+            int32_t a;
+            if (MODE == 1) a = actions[i];
+            else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
+                                            (uint32_t)d_ep, (uint32_t)p.n_rates);
+            if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;
+            flags = kRecValid;
+            abrx::Download d; d.dl = 0.0; d.n_dl = 0; d.hit = false;
+            if (a < 0 || a >= p.n_rates) flags |= kRecBadAct;
+            else d = abrx::lanej_download(cur, tb, st, d_k, p.ladder[a] * p.chunk_length /* :156 */);
+            if (d.hit) flags |= kRecHit;
+            m.dl[cb][l] = d.dl; m.n_dl[cb][l] = d.n_dl; m.k_start[cb][l] = d_k;
+            m.step[cb][l] = d_step; m.action[cb][l] = a; m.avail_next[cb][l] = st.avail_next;
+            issued_step = d_step; issued_k = d_k;
+            // ---- where the NEXT download starts, if nothing gates it ----
+            if (!d.hit) d_alive = false;           // bad action or max_ticks: the player retires the lane
+            else {
+                d_step++;
+                d_chunk++;
+                d_k = max(d_k + d.n_dl, st.avail_next);         // completing tick + 1, or availability (:143)
+                if (d_chunk >= V) {
+                    if (p.auto_reset) {            // a fresh episode: clock, cursor and chunk ids restart
+                        d_chunk = 0; d_ep++; d_k = tb.avail_tick[0];
+                        abrx::cursor_init(cur, offset0);
+                    } else d_alive = false;
+                }
+            }
+        }
+        m.flags[cb][l] = flags;
+        SPLIT_STAMP_T1
+        __syncthreads();
+        SPLIT_STAMP_T2
+        if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
+        // ---- validate the record just issued against the player's true call site ----
+        if (!m.fb_alive[cb][l]) d_alive = false;
+        else if (issued_step != m.fb_step[cb][l] || issued_k != m.fb_k[cb][l]) {
+            // gated by buffer_full: take the player's word for where the download starts and
+            // redo it from the cursor it started from
+            d_alive = true;
+            d_step = m.fb_step[cb][l]; d_k = m.fb_k[cb][l];
+            d_chunk = m.fb_chunk[cb][l]; d_ep = m.fb_episode[cb][l];
+            if (issued_step == d_step) { cur.j = snap_j; cur.tpos = snap_tpos; }
+            issued_step = -1;
+        }
+    }
+    SPLIT_STAMP_OUT(0)
+    if (in_range && was_alive) { p.j[i] = cur.j; p.tpos[i] = cur.tpos; }
+}
+
+// Wave 1 of a workgroup: the player side (and all outputs) of the same 64 lanes.
+template <int MODE>
+__device__ __forceinline__ void split_role_player(
+    const EnvParams &p, SplitMail &m, float *__restrict__ obs_out, float *__restrict__ reward_out,
+    uint8_t *__restrict__ done_out, int32_t *__restrict__ actions_out, int32_t n_total) {
+    const int l = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 64 + l;
+    const bool in_range = i < p.n_lanes;
+    const int32_t V = p.video_length;
+    const abrx::Tables tb = make_tables(p);
+    LaneJ s;
+    s.cur.j = 0; s.cur.tpos = 0; s.cur.tlen = 1; s.cur.trace = p.traces;
+    uint8_t done = 0;
+    int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, b_step = 0;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, g_su_obs = 0.0, g_rb_obs = 0.0;
+    bool b_alive = false, was_done = true;
+    if (in_range) {
+        done = p.done[i];
+        was_done = done != 0;
+        lanej_load(s, p, i);
+        n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
+        last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+        g_su_obs = p.G[n_su_obs]; g_rb_obs = p.G[n_rb_obs];
+        b_alive = !done;
+    }
+    SPLIT_STAMP_DECL
+    for (int32_t t = 0;; t++) {
+        const int cb = t & 1, pb = (t + 1) & 1;    // this iteration's / the previous one's slot
+        SPLIT_STAMP_T0
+        if (b_alive && b_step < n_total && t >= 1) {
+            const int32_t fl = m.flags[pb][l];
+            // accept the download only if it started at exactly this lane's call-site tick
+            if ((fl & kRecValid) && m.step[pb][l] == b_step && m.k_start[pb][l] == s.k) {
+                const int64_t o = (int64_t)b_step * p.n_lanes + i;
+                float *obs = obs_out ? obs_out + (int64_t)b_step * ABR_OBS_DIM * p.n_lanes : nullptr;
+                const int32_t a = m.action[pb][l];
+                if (fl & kRecBadAct) {
+                    done |= ABR_DONE_BADACT;
+                    if (reward_out) reward_out[o] = 0.0f;
+                    if (done_out) done_out[o] = done;
+                    write_obs_j(s, p, i, obs, last_bw);
+                    b_alive = false;
+                } else {
+                    abrx::Download d;
+                    d.dl = m.dl[pb][l]; d.n_dl = m.n_dl[pb][l]; d.hit = (fl & kRecHit) != 0;
+                    const int32_t prev_action = s.last_action;
+                    const int32_t chunk = s.chunk_id;
+                    const abrx::StepResult r =
+                        abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
+                    double var = 0.0;
+                    if (r.hit) {
+                        const int64_t h = (int64_t)chunk * p.n_lanes + i;
+                        p.bw_hist[h] = r.bw;                                   // :164
+                        p.action_hist[h] = (uint8_t)a;                         // :165
+                        last_bw = r.bw;
+                        hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
+                        hist_n = hist_n + 1.0;
+                        if (prev_action >= 0) var = fabs(p.ladder[a] - p.ladder[prev_action]);
+                    }
+                    // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
+                    const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
+                    const double rew = p.wr * (g_rb - g_rb_obs) + p.ws * (g_su - g_su_obs) + p.wv * var;
+                    if (r.ended) done |= ABR_DONE_EPISODE;
+                    if (r.timeout) done |= ABR_DONE_TIMEOUT;
+                    if (reward_out) reward_out[o] = (float)rew;
+                    if (done_out) done_out[o] = done;
+                    n_su_obs = s.n_su; n_rb_obs = s.n_rb;
+                    g_su_obs = g_su; g_rb_obs = g_rb;
+                    if (r.ended || r.timeout) {
+                        p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
+                        p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                        p.ep_qoe_terms[2 * p.n_lanes + i] =
+                            p.lane_speeds ? avg_latency_from(s.sd, s.pt, s.sumk, s.n_play)
+                                          : lane_avg_latency(p, s.sumk, s.n_play);
+                        if (p.auto_reset && r.ended) {
+                            // re-arm: this step's obs is the new episode's first call site
+                            for (int c = 0; c < V; c++)
+                                p.ep_actions[(int64_t)c * p.n_lanes + i] =
+                                    p.action_hist[(int64_t)c * p.n_lanes + i];
+                            abrx::lanej_init_player(s, tb);
+                            episode_no++;
+                            n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
+                            last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                            done = 0;
+                            if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
+                        }
+                    }
+                    write_obs_j(s, p, i, obs, last_bw);
+                    if (done) b_alive = false;
+                }
+                b_step++;
+            }
+        }
+        // ---- tell the download side where this lane really is ----
+        const bool more = b_alive && b_step < n_total;
+        m.fb_step[cb][l] = b_step; m.fb_k[cb][l] = s.k; m.fb_chunk[cb][l] = s.chunk_id;
+        m.fb_episode[cb][l] = episode_no; m.fb_alive[cb][l] = more ? 1 : 0;
+        const bool any = __any(more) != 0;
+        if (l == 0) m.any_alive[cb] = any ? 1 : 0;
+        SPLIT_STAMP_T1
+        __syncthreads();
+        SPLIT_STAMP_T2
+        if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
+    }
+    SPLIT_STAMP_OUT(3)
+    if (in_range) {
+        if (!was_done) {
+            lanej_store_player(s, p, i);
+            p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
+            p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+            p.done[i] = done;
+        }
+        // lanes that were already finished (or finished early) report their terminal record
+        // for the remaining steps
+        for (int32_t t2 = b_step; t2 < n_total; t2++) {
+            const int64_t o = (int64_t)t2 * p.n_lanes + i;
+            if (reward_out) reward_out[o] = 0.0f;
+            if (done_out) done_out[o] = done;
+            if (MODE == 2 && actions_out) actions_out[o] = -1;
+            write_obs_j(s, p, i, obs_out ? obs_out + (int64_t)t2 * ABR_OBS_DIM * p.n_lanes : nullptr,
+                        last_bw);
+        }
+    }
+}
+
+// MODE 1: one externally supplied action per lane; MODE 2: fused random-policy rollout
+template <int MODE>
+__global__ __launch_bounds__(128) void env_split_kernel(
+    EnvParams p, const int32_t *__restrict__ actions, float *__restrict__ obs_out,
+    float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
+    int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
+    __shared__ SplitMail m;
+    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    // the role is wave-uniform: each wave runs exactly one of the two loops
+    if (threadIdx.x < 64) split_role_download<MODE>(p, m, actions, actions_out, n_total, seed);
+    else split_role_player<MODE>(p, m, obs_out, reward_out, done_out, actions_out, n_total);
+}
+
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -829,6 +1108,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     if (!e) return fail(ABR_E_INVALID, "out of host memory");
     memset(e, 0, sizeof(*e));
     e->cfg = *cfg;
+    e->impl = 2;
     e->workspace_bytes = L.total;
     EnvParams &p = e->p;
     p.n_rates = cfg->n_rates; p.video_length = cfg->video_length; p.max_ticks = mt;
@@ -883,10 +1163,11 @@ extern "C" int abr_env_destroy(abr_env *env) {
     return ABR_OK;
 }
 
-// 0 = event-driven kernels (default), 1 = tick-by-tick kernels (kept as a cross-check)
+// 2 = role-split event-driven kernels (default), 0 = event-driven, one thread per lane,
+// 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl != 0 && impl != 1) return fail(ABR_E_INVALID, "impl must be 0 (jump) or 1 (tick)");
+    if (impl < 0 || impl > 2) return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick) or 2 (split)");
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -896,8 +1177,8 @@ extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
 // one constant play speed per lane (8f rank 3); nullptr restores the single config speed
 extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (speeds_dev && env->impl)
-        return fail(ABR_E_UNSUPPORTED, "per-lane speeds need the event-driven kernels (impl 0)");
+    if (speeds_dev && env->impl == 1)
+        return fail(ABR_E_UNSUPPORTED, "per-lane speeds need the event-driven kernels (impl 0 or 2)");
     // latched by the next FULL abr_env_reset: until then the running episodes keep the
     // speeds (and the carried play_time) they were started with
     env->pending_speeds = speeds_dev;
@@ -926,7 +1207,7 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
         env->p.lane_speeds = env->pending_speeds;
         env->speeds_dirty = false;
     }
-    hipLaunchKernelGGL(env->impl ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+    hipLaunchKernelGGL(env->impl == 1 ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, nullptr, trace_id_dev, start_offset_dev,
                        lane_mask_dev, obs_out_dev, nullptr, nullptr, nullptr, 0, 0ull);
     HIP_TRY(hipGetLastError());
@@ -937,9 +1218,14 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
                             float *reward_out_dev, uint8_t *done_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
-    hipLaunchKernelGGL(env->impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
-                       (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
-                       obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull);
+    if (env->impl == 2)
+        hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
+                           (hipStream_t)stream, env->p, actions_dev, obs_out_dev, reward_out_dev,
+                           done_out_dev, nullptr, 1, 0ull);
+    else
+        hipLaunchKernelGGL(env->impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+                           (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
+                           obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull);
     HIP_TRY(hipGetLastError());
     return ABR_OK;
 }
@@ -949,9 +1235,14 @@ extern "C" int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed,
                                    uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
-    hipLaunchKernelGGL(env->impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
-                       (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
-                       obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
+    if (env->impl == 2)
+        hipLaunchKernelGGL(env_split_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
+                           (hipStream_t)stream, env->p, nullptr, obs_out_dev, reward_out_dev,
+                           done_out_dev, actions_out_dev, n_steps, seed);
+    else
+        hipLaunchKernelGGL(env->impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+                           (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
+                           obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
     HIP_TRY(hipGetLastError());
     return ABR_OK;
 }
@@ -971,6 +1262,10 @@ extern "C" int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream) 
     HIP_TRY(hipGetLastError());
     return ABR_OK;
 }
+
+#ifdef ABR_SPLIT_STAMPS
+extern "C" void *abr_debug_stamp_row(abr_env *env) { return env->p.ep_qoe_terms + 3 * env->p.n_lanes; }
+#endif
 
 extern "C" int abr_env_get_state(abr_env *env, abr_env_state_view *v) {
     if (!env || !v) return fail(ABR_E_INVALID, "NULL argument");

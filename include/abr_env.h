@@ -135,9 +135,11 @@ int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
  * Event-driven kernels only. */
 int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);   /* latched: see above */
 
-/* Which kernels serve reset/step: 0 (default) = event-driven, exact closed-form
- * stepping of the float64 tick sequences; 1 = one loop trip per 0.01 s tick.  Both
- * produce identical state; 1 exists as an independent cross-check. */
+/* Which kernels serve reset/step: 2 (default) = event-driven (exact closed-form stepping
+ * of the float64 tick sequences) with each lane's download side and player side on two
+ * waves of one workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per
+ * 0.01 s tick.  All three produce identical state and outputs (the workspace is
+ * interchangeable between them); 0 and 1 exist as independent cross-checks. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 
 /*

@@ -1,0 +1,34 @@
+"""Per-role cycle stamps of the role-split env kernel (diagnostic build libabr_hip_stamps.so):
+how long each wave works per iteration and how long it waits at the workgroup barrier.
+  ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py [lanes]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+import abrsimulator_amd as A  # noqa: E402
+from abrsimulator_amd import _lib  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+traces = B.synth_traces(False)
+tid, off = B.lane_assignment(0, N, traces)
+env = A.BatchedABREnv(A.MPD(B.V, B.L, B.MAX_BUFFER, B.START_UP, A.Chunk(B.LADDER)), A.QOEMetric(*B.WEIGHTS),
+                      A.NetworkInfo(B.INTERVAL, traces), N, auto_reset=True)
+env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+for _ in range(3):
+    env.step_random(48, 1, want_actions=False)
+torch.cuda.synchronize()
+fn = env.lib.abr_debug_stamp_row
+fn.restype = C.c_void_p
+fn.argtypes = [C.c_void_p]
+row = env._view(fn(env._h), torch.float64, (N,)).cpu().numpy().reshape(-1, 64)[:, :6]
+names = ["D work", "D wait", "D iters", "P work", "P wait", "P iters"]
+for c, n in enumerate(names):
+    print(f"{n:8s} mean {row[:, c].mean():12.0f}  min {row[:, c].min():12.0f}  max {row[:, c].max():12.0f}")
+it = row[:, 2].mean()
+print(f"per iteration: D work {row[:,0].mean()/it:.0f} wait {row[:,1].mean()/it:.0f} | "
+      f"P work {row[:,3].mean()/it:.0f} wait {row[:,4].mean()/it:.0f} cycles; iterations/launch {it:.1f}")
