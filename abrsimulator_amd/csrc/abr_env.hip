@@ -28,6 +28,40 @@
 #include <vector>
 
 #include "abr_env.h"
+
+#ifdef ABR_SPLIT_STAMPS
+// diagnostic build only: cycle accumulators per code region.  Lane 0 of each wave adds the
+// cycles since that wave's previous stamp to region n, in LDS; the totals go to global memory
+// once, at the end of the kernel (ABR_STAMP_FLUSH); read with abr_debug_read_stamps.
+__device__ unsigned long long g_st_acc[32];
+__shared__ unsigned long long g_sh_st[2][33];
+#define ABR_STAMP(n)                                                                           \
+    do {                                                                                       \
+        if ((threadIdx.x & 63) == 0) {                                                         \
+            const unsigned long long t_ = (unsigned long long)__builtin_amdgcn_s_memtime();    \
+            const unsigned w_ = (threadIdx.x >> 6) & 1;                                        \
+            g_sh_st[w_][n] += t_ - g_sh_st[w_][32];                                            \
+            g_sh_st[w_][32] = t_;                                                              \
+        }                                                                                      \
+    } while (0)
+#define ABR_STAMP_INIT()                                                                       \
+    do {                                                                                       \
+        if ((threadIdx.x & 63) == 0) {                                                         \
+            for (int q_ = 0; q_ < 32; q_++) g_sh_st[(threadIdx.x >> 6) & 1][q_] = 0;           \
+            g_sh_st[(threadIdx.x >> 6) & 1][32] = (unsigned long long)__builtin_amdgcn_s_memtime(); \
+        }                                                                                      \
+    } while (0)
+#define ABR_STAMP_FLUSH()                                                                      \
+    do {                                                                                       \
+        if ((threadIdx.x & 63) == 0)                                                           \
+            for (int q_ = 0; q_ < 32; q_++)                                                    \
+                if (g_sh_st[(threadIdx.x >> 6) & 1][q_])                                       \
+                    atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) & 1][q_]);             \
+    } while (0)
+#else
+#define ABR_STAMP_INIT()
+#define ABR_STAMP_FLUSH()
+#endif
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
@@ -738,14 +772,17 @@ __device__ __forceinline__ void split_role_download(
         d_alive = was_alive = !p.done[i];
     }
     SPLIT_STAMP_DECL
+    ABR_STAMP_INIT();
     for (int32_t t = 0;; t++) {
         const int cb = t & 1;                      // this iteration's mailbox slot
         SPLIT_STAMP_T0
         // ---- download of step d_step, started at its (predicted) call site ----
         int32_t flags = 0;
+        ABR_STAMP(0);
         if (d_alive && d_step < n_total) {
             snap_j = cur.j; snap_tpos = cur.tpos;
             const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
+            ABR_STAMP(1);
             int32_t a;
             if (MODE == 1) a = actions[i];
             else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
@@ -753,8 +790,10 @@ __device__ __forceinline__ void split_role_download(
             if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;
             flags = kRecValid;
             abrx::Download d; d.dl = 0.0; d.n_dl = 0; d.hit = false;
+            ABR_STAMP(2);
             if (a < 0 || a >= p.n_rates) flags |= kRecBadAct;
             else d = abrx::lanej_download(cur, tb, st, d_k, p.ladder[a] * p.chunk_length /* :156 */);
+            ABR_STAMP(3);
             if (d.hit) flags |= kRecHit;
             m.dl[cb][l] = d.dl; m.n_dl[cb][l] = d.n_dl; m.k_start[cb][l] = d_k;
             m.step[cb][l] = d_step; m.action[cb][l] = a; m.avail_next[cb][l] = st.avail_next;
@@ -774,9 +813,11 @@ __device__ __forceinline__ void split_role_download(
             }
         }
         m.flags[cb][l] = flags;
+        ABR_STAMP(4);
         SPLIT_STAMP_T1
         __syncthreads();
         SPLIT_STAMP_T2
+        ABR_STAMP(5);
         if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
         // ---- validate the record just issued against the player's true call site ----
         if (!m.fb_alive[cb][l]) d_alive = false;
@@ -791,6 +832,7 @@ __device__ __forceinline__ void split_role_download(
         }
     }
     SPLIT_STAMP_OUT(0)
+    ABR_STAMP_FLUSH();
     if (in_range && was_alive) { p.j[i] = cur.j; p.tpos[i] = cur.tpos; }
 }
 
@@ -820,9 +862,11 @@ __device__ __forceinline__ void split_role_player(
         b_alive = !done;
     }
     SPLIT_STAMP_DECL
+    ABR_STAMP_INIT();
     for (int32_t t = 0;; t++) {
         const int cb = t & 1, pb = (t + 1) & 1;    // this iteration's / the previous one's slot
         SPLIT_STAMP_T0
+        ABR_STAMP(8);
         if (b_alive && b_step < n_total && t >= 1) {
             const int32_t fl = m.flags[pb][l];
             // accept the download only if it started at exactly this lane's call-site tick
@@ -841,8 +885,10 @@ __device__ __forceinline__ void split_role_player(
                     d.dl = m.dl[pb][l]; d.n_dl = m.n_dl[pb][l]; d.hit = (fl & kRecHit) != 0;
                     const int32_t prev_action = s.last_action;
                     const int32_t chunk = s.chunk_id;
+                    ABR_STAMP(9);
                     const abrx::StepResult r =
                         abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
+                    ABR_STAMP(13);
                     double var = 0.0;
                     if (r.hit) {
                         const int64_t h = (int64_t)chunk * p.n_lanes + i;
@@ -862,6 +908,7 @@ __device__ __forceinline__ void split_role_player(
                     if (done_out) done_out[o] = done;
                     n_su_obs = s.n_su; n_rb_obs = s.n_rb;
                     g_su_obs = g_su; g_rb_obs = g_rb;
+                    ABR_STAMP(14);
                     if (r.ended || r.timeout) {
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
@@ -881,8 +928,10 @@ __device__ __forceinline__ void split_role_player(
                             if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                         }
                     }
+                    ABR_STAMP(15);
                     write_obs_j(s, p, i, obs, last_bw);
                     if (done) b_alive = false;
+                    ABR_STAMP(16);
                 }
                 b_step++;
             }
@@ -893,12 +942,15 @@ __device__ __forceinline__ void split_role_player(
         m.fb_episode[cb][l] = episode_no; m.fb_alive[cb][l] = more ? 1 : 0;
         const bool any = __any(more) != 0;
         if (l == 0) m.any_alive[cb] = any ? 1 : 0;
+        ABR_STAMP(17);
         SPLIT_STAMP_T1
         __syncthreads();
         SPLIT_STAMP_T2
+        ABR_STAMP(18);
         if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
     }
     SPLIT_STAMP_OUT(3)
+    ABR_STAMP_FLUSH();
     if (in_range) {
         if (!was_done) {
             lanej_store_player(s, p, i);
@@ -1265,6 +1317,12 @@ extern "C" int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream) 
 
 #ifdef ABR_SPLIT_STAMPS
 extern "C" void *abr_debug_stamp_row(abr_env *env) { return env->p.ep_qoe_terms + 3 * env->p.n_lanes; }
+extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc), z, sizeof(z)); }
+    return 0;
+}
 #endif
 
 extern "C" int abr_env_get_state(abr_env *env, abr_env_state_view *v) {

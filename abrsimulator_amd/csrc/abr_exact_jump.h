@@ -79,6 +79,22 @@ ABR_HD double rcp_est(double d) {
 #endif
 }
 
+// (int32_t)v with saturation: NaN -> 0, below INT32_MIN -> INT32_MIN, above INT32_MAX ->
+// INT32_MAX.  v_cvt_i32_f64 does exactly that in one instruction; the C++ cast of an
+// out-of-range double is undefined, so the host build spells it out.
+ABR_HD int32_t sat_i32(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    if (!(v == v)) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int32_t)v;
+#endif
+}
+
 // Running state of one chain, so that a caller can interleave other work (the
 // download integration advances through trace intervals between segments).
 struct ChainState {
@@ -162,28 +178,34 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
             gap = x - lim;
         }
         const int32_t room = can ? n : 0;
-        double mf = gap * rcp_est(dm);
-        const double cap = (double)room;
-        mf = (mf > 0.0) ? mf : 0.0;      // also maps NaN to 0
-        mf = (mf > cap) ? cap : mf;
-        const int32_t m0 = (int32_t)mf;
+        // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0).
+        int32_t m0 = sat_i32(gap * rcp_est(dm));
+        m0 = (m0 > 0) ? m0 : 0;
+        m0 = (m0 < room) ? m0 : room;
         // Exact settlement (x + m*d is exact while it stays inside the binade).  The
-        // estimate is within one of the answer, so the answer is among base..base+2 with
-        // base = m0 - 1; the four candidates base..base+3 are evaluated independently
-        // (short dependency chain) and also prove the bracket: candidate 0 must be inside
-        // and candidate 3 outside, else the out-of-line exact search takes over.
+        // estimate is within one of the answer, so the answer is among bs..bs+2 with
+        // bs = m0 - 1; the four candidates bs..bs+3 also prove the bracket: candidate 0 must
+        // be inside and candidate 3 outside, else the out-of-line exact search takes over.
+        // Candidates 1..3 are formed by adding d to the previous one: identical to
+        // x + (bs+k)*d whenever the previous candidate is inside (both are then exact), and
+        // a candidate only counts if all before it are inside.
         const int32_t bs = (m0 > 0) ? m0 - 1 : 0;
-        const bool t0 = (bs == 0) | jump_inside<STOP>(x + (double)bs * d, lim, strict);
-        const double y1 = x + (double)(bs + 1) * d;
-        const double y2 = x + (double)(bs + 2) * d;
-        const double y3 = x + (double)(bs + 3) * d;
+        const double y0 = x + (double)bs * d;
+        const double y1 = y0 + d;
+        const double y2 = y1 + d;
+        const double y3 = y2 + d;
+        const bool t0 = (bs == 0) | jump_inside<STOP>(y0, lim, strict);
         const bool t1 = (bs + 1 <= room) & jump_inside<STOP>(y1, lim, strict);
         const bool t2 = (bs + 2 <= room) & jump_inside<STOP>(y2, lim, strict) & t1;
         const bool t3 = (bs + 3 <= room) & jump_inside<STOP>(y3, lim, strict) & t2;
         int32_t m = bs + (t1 ? 1 : 0) + (t2 ? 1 : 0);
+        double xj = t2 ? y2 : (t1 ? y1 : y0);
         const bool fine = t0 & !t3;
-        if (!fine) m = jump_fix<STOP>(x, d, lim, strict, m, room);
-        x = x + (double)m * d;           // m == 0 when !can
+        if (!fine) {
+            m = jump_fix<STOP>(x, d, lim, strict, m, room);
+            xj = x + (double)m * d;
+        }
+        x = xj;                          // == x when !can (m == 0)
         a = m;
     }
     // ---- one real addition ----

@@ -30,6 +30,10 @@
 
 #include "abr_exact_jump.h"
 
+#ifndef ABR_STAMP
+#define ABR_STAMP(n)               // cycle stamps exist only in the diagnostic build of abr_env.hip
+#endif
+
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
@@ -94,6 +98,28 @@ ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
     s.pt = x;
 }
 
+// buffer_level -= speed*dt per playing tick (:184) for up to m ticks, stopping right after the
+// first result <= 0 (:194).  Same contract as chain<STOP_LE>(b, -sd, 0.0, m, a).  Far from
+// zero the exact jumps do the work; within kDrainTail ticks of zero a binade lasts only a
+// few ticks (32, 16, 8, ...: one segment each), so the last stretch is plain subtractions --
+// the reference's own sequence.  The switch point affects speed only, never a result.
+constexpr int kDrainTail = 64;
+ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
+    ChainState cs;
+    cs.x = b_io; cs.d = 0.0; cs.inb = 0;
+    const double tail = (double)kDrainTail * sd;
+    int32_t a = 0;
+    bool below = false;
+    while (a < m && !below) a += chain_segment<STOP_LE>(cs, -sd, tail, m - a, below);
+    double b = cs.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    while (a < m && b > 0.0) { b = b - sd; a++; }
+    b_io = b; a_out = a;
+    return a > 0 && b <= 0.0;
+}
+
 // m full iterations: T4-T9 of a tick in which no chunk completes, then T1-T3 of the next
 ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     if (m <= 0) return;
@@ -108,7 +134,7 @@ ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     } else {
         int32_t a = 0;
         double b = s.buf;
-        const bool zero = chain<STOP_LE>(b, -s.sd, 0.0, m, a);                 // :184,:194
+        const bool zero = drain_to_zero(b, s.sd, m, a);                        // :184,:194
         lanej_play(s, t, a);
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
@@ -305,6 +331,7 @@ ABR_HD StepResult lanej_after_download(LaneJ &s, const Tables &t, const Download
     const double g_ndl = t.G[n_dl];           // download_time; loaded now, divided by much later
     // ---- buffer side of the ticks before the completing one ----
     lanej_idle(s, t, hit ? n_dl - 1 : n_dl);
+    ABR_STAMP(10);
     if (!hit) { r.timeout = true; return r; }
     // ---- the completing tick (:163-170, then :174-202) ----
     const bool playing = !(s.be || s.su);
@@ -323,11 +350,13 @@ ABR_HD StepResult lanej_after_download(LaneJ &s, const Tables &t, const Download
     s.avail_k = avail_next;
     r.ended = s.chunk_id >= t.V;                                             // :207-208
     r.timeout = !r.ended && s.k >= mt;
+    ABR_STAMP(11);
     if (!r.ended && !r.timeout) {
         s.n_su += s.su ? 1 : 0;                                              // T1 of the next tick
         s.n_rb += (!s.su && s.be) ? 1 : 0;
         r.timeout = !lanej_wait_call(s, t);                                  // phase B
     }
+    ABR_STAMP(12);
     return r;
 }
 

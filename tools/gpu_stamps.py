@@ -32,3 +32,17 @@ for c, n in enumerate(names):
 it = row[:, 2].mean()
 print(f"per iteration: D work {row[:,0].mean()/it:.0f} wait {row[:,1].mean()/it:.0f} | "
       f"P work {row[:,3].mean()/it:.0f} wait {row[:,4].mean()/it:.0f} cycles; iterations/launch {it:.1f}")
+
+rd = env.lib.abr_debug_read_stamps
+rd.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 32)()
+rd(buf, 1)
+env.step_random(48, 1, want_actions=False)
+rd(buf, 1)
+waves = N // 64
+regions = {1: "D begin_step loads", 2: "D philox", 3: "D download loop", 4: "D publish", 5: "D barrier wait",
+           0: "D validate+loop", 9: "P record read", 10: "P drain (download ticks)", 11: "P completing tick",
+           12: "P phase B wait_call", 13: "P return", 14: "P div+hist+reward", 15: "P episode end", 16: "P obs out",
+           17: "P feedback", 18: "P barrier wait", 8: "P loop"}
+for k in sorted(regions):
+    print(f"  [{k:2d}] {regions[k]:28s} {buf[k] / waves / 49:9.0f} cycles / wave / iteration")
