@@ -3,19 +3,29 @@
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  BASELINE.json's 1/2/4/8-GPU scaling curve on 1 048 576 lanes: add --total-lanes 1048576.
 
 Workloads (config.workload in the JSON line)
   env_random  (default; BASELINE.json configs[1]) 65 536 lanes per GPU, built-in
               random-bitrate policy, 1 024 synthetic 1 000-pt traces.  A "step" is one
-              chunk decision for every lane; `--fuse F` decisions share one kernel launch.
-              metric = env-steps/s = lanes * K / time.
+              chunk decision for every lane; min(--fuse, --steps) decisions share one kernel
+              launch (config.fuse reports the number actually fused).
+              metric = env-steps/s = lanes * K / time.  At N = 1 the same process then
+              measures the other half of BASELINE.json's metric -- MPC combos/s at horizon 5
+              (configs[2]) -- and reports it under "secondary" in the same JSON line.
   mpc         (configs[2], MPC half) 65 536 lanes x MPC horizon 5 over 6 rates:
               a step is one abr_mpc_select over all lanes; metric = combos/s.
   env_mpc     (configs[2]) MPC-driven rollout: every step = mpc_select + env step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), carrying
-`roofline` (dominant kernel, HIP-event timed inside the timed region) and
-`cpu_baseline` (the C oracle on the host cores, bounded sample; rank 0, N=1 only).
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both
+sides, max over ranks.  When K < --min-timed-steps that region is repeated (`repeats`) and the
+median repeat is reported, every repeat bracketed the same way.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline`
+(dominant kernel, HIP-event timed inside the timed region; `binding` = what limits it, from
+the committed SQ counters of the same kernel / lanes / fuse) and `cpu_baseline` (the C oracle
+on the host cores, bounded sample; rank 0, N=1 only; `affinity_cores` = cores visible,
+`cores` = threads used).
 """
 import argparse
 import json
@@ -57,9 +67,11 @@ def lane_assignment(lane0, n, traces):
 
 
 def host_cores():
-    """Threads for the CPU baseline: the GPU box exposes every host core in the affinity
-    mask but grants one GPU's share of CPU time (16 cores); ABR_BENCH_CORES overrides."""
-    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("ABR_BENCH_CORES", "16"))))
+    """(threads used, cores in the affinity mask).  The GPU box exposes every host core in the
+    affinity mask but grants one GPU's share of CPU time (16 cores); ABR_BENCH_CORES overrides
+    the thread count."""
+    aff = len(os.sched_getaffinity(0))
+    return max(1, min(aff, int(os.environ.get("ABR_BENCH_CORES", "16")))), aff
 
 
 def cpu_baseline_env(traces, seed, budget_s=12.0):
@@ -68,7 +80,7 @@ def cpu_baseline_env(traces, seed, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    cores = host_cores()
+    cores, aff = host_cores()
     cfg = O.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, INTERVAL, WEIGHTS, 1.0)
 
     def prep(lane0, n):
@@ -91,7 +103,7 @@ def cpu_baseline_env(traces, seed, budget_s=12.0):
         list(ex.map(run, inputs))
     wall = time.perf_counter() - t0
     n_steps = cores * per_core * V
-    out = dict(value=n_steps / wall, unit="env-steps/s", cores=cores, kind="port",
+    out = dict(value=n_steps / wall, unit="env-steps/s", cores=cores, affinity_cores=aff, kind="port",
                sample=f"{cores * per_core} lanes x {V}-chunk episodes ({n_steps} env-steps) of the "
                       f"same workload, C oracle -O2 -ffp-contract=off, one thread per core, "
                       f"{wall:.1f} s wall")
@@ -116,7 +128,7 @@ def cpu_baseline_mpc(budget_s=10.0):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    cores = host_cores()
+    cores, aff = host_cores()
     mc = O.mpc_cfg(len(LADDER), 5, V, L, MAX_BUFFER, 1.0, 4.3, 0.0)
     br = np.tile(np.array(LADDER), (V, 1))
     sz = br * L
@@ -135,9 +147,37 @@ def cpu_baseline_mpc(budget_s=10.0):
         list(ex.map(lambda c: run(per_core), range(cores)))
     wall = time.perf_counter() - t0
     combos = cores * per_core * 6 ** 5
-    return dict(value=combos / wall, unit="combos/s", cores=cores, kind="port",
+    return dict(value=combos / wall, unit="combos/s", cores=cores, affinity_cores=aff, kind="port",
                 sample=f"{cores * per_core} lane decisions x 7776 combos, C oracle (literal "
                        f"objective per combo, no prefix sharing), {wall:.1f} s wall")
+
+
+def _load_binding(kernel, lanes, fuse):
+    """What actually binds the env kernel, from the committed SQ counter profile of the same
+    (kernel, lanes, fuse): vector-issue utilisation and active lanes per vector instruction."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not name.endswith("_sq_counters.json"):
+            continue
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel and d.get("lanes") == lanes and d.get("fuse") == fuse:
+            b = dict(d.get("binding", {}))
+            b["source"] = "profiles/" + name
+            return b
+    return None
+
+
+def _load_traffic(workload, kernel, lanes, fuse):
+    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(tj)).get(workload)
+    except Exception:
+        return None
+    if t and t.get("fuse") == fuse and t.get("lanes") == lanes and t.get("kernel") == kernel:
+        return t
+    return None
 
 
 def main():
@@ -145,24 +185,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4800)
     ap.add_argument("--warmup", type=int, default=480)
-    ap.add_argument("--fuse", type=int, default=48, help="chunk decisions per kernel launch (48 = one episode)")
+    ap.add_argument("--fuse", type=int, default=48,
+                    help="chunk decisions per kernel launch (48 = one episode; 1 = one launch and one "
+                         "all-gather per decision, BASELINE.json configs[3] taken literally)")
     ap.add_argument("--lanes-per-gpu", type=int, default=65536)
     ap.add_argument("--total-lanes", type=int, default=0,
-                    help="strong scaling: split this many lanes over the GPUs (e.g. 1048576, the "
-                         "BASELINE.json scaling curve) instead of a fixed count per GPU")
+                    help="strong scaling: split this many lanes over the GPUs.  The BASELINE.json scaling "
+                         "curve is `--gpus N --total-lanes 1048576` for N = 1, 2, 4, 8")
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--impl", default="split", choices=["split", "jump", "tick"])
+    ap.add_argument("--min-timed-steps", type=int, default=960,
+                    help="when --steps is smaller than this the timed region of exactly --steps steps is "
+                         "repeated (each repeat bracketed by barrier + synchronize) and the MEDIAN repeat "
+                         "is reported, so that one sub-millisecond launch is not the whole sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="env_random, N=1: skip the MPC combos/s half of BASELINE.json's metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
     ap.add_argument("--graph", action="store_true",
                     help="env_random, N=1: capture one launch in a HIP graph and replay it "
                          "(removes the host launch path; matters at --fuse 1)")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    # ---- launcher environment first: nothing below may touch the GPU before this is settled ----
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,28 +217,33 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+    if a.total_lanes and a.total_lanes % world:
+        raise SystemExit("--total-lanes must divide evenly over the GPUs (equal gather shapes)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: read when HSA initialises
     # rehearsal knobs (a 1-GPU box cannot run RCCL with 2 ranks): ABR_BENCH_ONE_DEVICE=1 puts every
     # rank on cuda:0, ABR_BENCH_BACKEND=gloo swaps the backend.  The driver's runs use neither.
     if os.environ.get("ABR_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = "none"
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("ABR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
         else:
             dist.init_process_group(backend)
 
     import abrsimulator_amd as A
     from abrsimulator_amd._lib import OBS_DIM
+    from abrsimulator_amd.sharding import ObsRewardGather, make_slab, shard_range
 
-    from abrsimulator_amd.sharding import shard_range
     if a.total_lanes:
         lane0, N = shard_range(a.total_lanes, world, rank)       # strong scaling
-        if a.total_lanes % world:
-            raise SystemExit("--total-lanes must divide evenly over the GPUs (equal gather shapes)")
     else:
         N = a.lanes_per_gpu                                      # weak scaling (default)
         lane0 = rank * N
@@ -199,8 +251,10 @@ def main():
     tid, off = lane_assignment(lane0, N, traces)
     mpd = A.MPD(V, L, MAX_BUFFER, START_UP, A.Chunk(LADDER))
     env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
-                          auto_reset=True, lane_id_base=lane0)
+                          auto_reset=True, lane_id_base=lane0, impl=a.impl)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    env_kernel = {"split": "env_split_kernel<2>", "jump": "env_jump_kernel<2>",
+                  "tick": "env_advance_kernel<2>"}[a.impl]
 
     def barrier():
         if world > 1:
@@ -209,22 +263,44 @@ def main():
 
     K, W = a.steps, a.warmup
     ev = []
-    extra = {}
+    gat = None
+
+    def mpc_setup():
+        player = A.EnvPlayer(env, mpd=A.MPD(V, L, MAX_BUFFER, START_UP,
+                                            [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
+                             qoe=A.QOEMetric(4.3, 1.0, 0.0))
+        ctl = A.BatchedMPCController(player, horizon=5, clip_horizon=True, device=dev)
+        # give every lane a history first (the reference divides by zero on an empty one, D13)
+        env.step_random(3, a.seed)
+        return player, ctl, player.hist_n.clone(), player.hist_sum_inv.clone()
+
+    def mpc_runner(player, ctl, hist_n0, hist_s0, events, drive_env):
+        def run(n_steps, timed):
+            for _ in range(n_steps):
+                if not drive_env:
+                    player.hist_n.copy_(hist_n0); player.hist_sum_inv.copy_(hist_s0)
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                act = ctl.next_bitrate()
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    events.append((e0, e1, 1))
+                if drive_env:
+                    env.step(torch.clamp(act, min=0))
+        return run
 
     if a.workload == "env_random":
-        F = max(1, min(a.fuse, K))
-        bufs = [dict(obs=torch.empty(F, OBS_DIM, N, dtype=torch.float32, device=dev),
-                     reward=torch.empty(F, N, dtype=torch.float32, device=dev),
-                     done=torch.empty(F, N, dtype=torch.uint8, device=dev), actions=None)
-                for _ in range(2)]
+        F = max(1, min(a.fuse, K))            # decisions actually fused into one launch
+        slabs = [make_slab(F, OBS_DIM, N, dev) for _ in range(2)]
+        bufs = [dict(obs=o, reward=r, done=torch.empty(F, N, dtype=torch.uint8, device=dev), actions=None)
+                for (_, o, r, _) in slabs]
         gather = world > 1 and not a.no_gather
         if gather:
-            # the one collective of the path: per launch, all-gather of (obs, reward) on a side
-            # stream, overlapped with the next launch (double-buffered).  obs = the observation
-            # every lane ends the launch with (what an off-GPU policy needs to act next; the
-            # intermediate observations of a fused launch are consumed on-device by the built-in
-            # policy and stay in the local slab); reward = all F per-step rewards.
-            from abrsimulator_amd.sharding import ObsRewardGather
+            # THE one collective of the path: per launch, ONE all-gather of the packed slab
+            # [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with the
+            # next launch (double-buffered).  The intermediate observations of a fused launch are
+            # consumed on-device by the built-in policy and stay in the local slab; at --fuse 1
+            # every observation is gathered (configs[3] literally).
             gat = ObsRewardGather((OBS_DIM, N), (F, N), dev)
 
         graph = None
@@ -260,7 +336,7 @@ def main():
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
                     ev.append((e0, e1, f))
                 if gather and f == F:
-                    gat.gather(b, bufs[b]["obs"][F - 1], bufs[b]["reward"])
+                    gat.gather(b, slabs[b][3])
                 left -= f
                 it += 1
             if gather:
@@ -269,27 +345,9 @@ def main():
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"
     else:
-        player = A.EnvPlayer(env, mpd=A.MPD(V, L, MAX_BUFFER, START_UP,
-                                            [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
-                             qoe=A.QOEMetric(4.3, 1.0, 0.0))
-        ctl = A.BatchedMPCController(player, horizon=5, clip_horizon=True, device=dev)
-        # give every lane a history first (the reference divides by zero on an empty one, D13)
-        env.step_random(3, a.seed)
-        hist_n0, hist_s0 = player.hist_n.clone(), player.hist_sum_inv.clone()
-
-        def run(n_steps, timed):
-            for _ in range(n_steps):
-                if a.workload == "mpc":
-                    player.hist_n.copy_(hist_n0); player.hist_sum_inv.copy_(hist_s0)
-                if timed:
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
-                act = ctl.next_bitrate()
-                if timed:
-                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
-                    ev.append((e0, e1, 1))
-                if a.workload == "env_mpc":
-                    env.step(torch.clamp(act, min=0))
-
+        F = 1
+        player, ctl, hn0, hs0 = mpc_setup()
+        run = mpc_runner(player, ctl, hn0, hs0, ev, a.workload == "env_mpc")
         if a.workload == "mpc":
             units_per_step = N * world * 6 ** 5
             unit, metric = "combos/s", "mpc_combos_per_sec"
@@ -297,21 +355,29 @@ def main():
             units_per_step = N * world
             unit, metric = "env-steps/s", "env_steps_per_sec_mpc_policy"
 
-    run(W, False)
-    barrier()
-    t0 = time.perf_counter()
-    run(K, True)
-    barrier()
-    t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    def timed_region(runner, n_steps):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        runner(n_steps, True)
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
 
-    kern_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
-    avg_launch_s = float(np.mean(kern_ms)) * 1e-3
-    f_per_launch = float(np.mean([f for _, _, f in ev]))
-    if a.workload == "env_random":
+    run(W, False)
+    repeats = max(1, -(-a.min_timed_steps // K)) if K < a.min_timed_steps else 1
+    times = [timed_region(run, K) for _ in range(repeats)]
+    elapsed = float(np.median(times))
+
+    def launch_stats(events):
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+        return float(np.mean(ms)) * 1e-3, float(np.mean([f for _, _, f in events]))
+
+    avg_launch_s, f_per_launch = launch_stats(ev)
+
+    def env_roofline():
         # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
         # launch; per decision: obs 32 + reward 4 + done 1 out, previous_bitrates 1 +
         # previous_bandwidths 8 appended, and the trace points walked (8 B bandwidth + 4 B
@@ -319,59 +385,89 @@ def main():
         pts = 4.07 * (8 + 4)
         per_decision = 32 + 4 + 1 + 1 + 8 + pts
         alg_bytes = N * (2 * STATE_BYTES + f_per_launch * per_decision)
-        roof = dict(bound="hbm", kernel="env_jump_kernel<2>",
+        roof = dict(bound="hbm", kernel=env_kernel,
                     achieved=alg_bytes / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     traffic=None, avg_launch_us=avg_launch_s * 1e6,
-                    algorithmic_bytes_per_launch=alg_bytes,
-                    note="tick-exact semantics make this kernel VALU/latency-bound, not HBM-bound "
-                         "(SURVEY.md 8d); the HBM fraction is reported as mandated")
+                    algorithmic_bytes_per_launch=alg_bytes, decisions_per_launch=f_per_launch,
+                    note="tick-exact semantics make this kernel vector-issue / latency-bound, not "
+                         "HBM-bound (SURVEY.md 8d); the HBM fraction is reported as mandated, and "
+                         "`binding` names the resource that actually limits it")
         roof["frac"] = roof["achieved"] / roof["peak"]
-    else:
+        t = _load_traffic("env_random", env_kernel, N, int(round(f_per_launch)))
+        if t:
+            roof["traffic"] = t["bytes_per_launch"]
+            roof["traffic_source"] = t.get("source")
+        b = _load_binding(env_kernel, N, int(round(f_per_launch)))
+        if b:
+            roof["binding"] = b
+        return roof
+
+    def mpc_roofline(launch_s):
         # K3 is fp64-VALU-bound.  Executed work with prefix sharing: 7 776 leaves x
         # 9 flop + 1 554 inner nodes x 13 flop = 90.2 kflop per lane decision (the reference's
         # from-scratch formulation is 99 flop x 7 776 combos = 770 kflop).  No FMA may
         # be used (-ffp-contract=off is the parity contract), so 50 % of the FMA peak is the ceiling.
         flops = N * (7776 * 9.0 + 1554 * 13.0)
         roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5,6>",
-                    achieved=flops / avg_launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                    traffic=None, avg_launch_us=avg_launch_s * 1e6,
-                    reference_formulation_tflops=N * 6 ** 5 * 99.0 / avg_launch_s / 1e12,
+                    achieved=flops / launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                    traffic=None, avg_launch_us=launch_s * 1e6,
+                    reference_formulation_tflops=N * 6 ** 5 * 99.0 / launch_s / 1e12,
                     note="executed fp64 flop (prefix-sharing DFS) against the FMA peak; "
                          "add/mul only, so 0.5 is the ceiling")
         roof["frac"] = roof["achieved"] / roof["peak"]
-    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tj):
-        try:
-            t = json.load(open(tj)).get(a.workload)
-            if t and t.get("fuse") == (a.fuse if a.workload == "env_random" else 1) \
-                    and t.get("lanes") == N:
-                roof["traffic"] = t["bytes_per_launch"]
-                roof["traffic_source"] = t.get("source")
-        except Exception:
-            pass
+        t = _load_traffic("mpc", "mpc_select_kernel<5,6>", N, 1)
+        if t:
+            roof["traffic"] = t["bytes_per_launch"]
+            roof["traffic_source"] = t.get("source")
+        return roof
+
+    roof = env_roofline() if a.workload == "env_random" else mpc_roofline(avg_launch_s)
+
+    # ---- the other half of BASELINE.json's metric, same process, same JSON line ----
+    secondary = None
+    if a.workload == "env_random" and world == 1 and not a.no_secondary:
+        ev2 = []
+        player, ctl, hn0, hs0 = mpc_setup()
+        run2 = mpc_runner(player, ctl, hn0, hs0, ev2, False)
+        K2, W2 = 30, 5
+        run2(W2, False)
+        el2 = timed_region(run2, K2)
+        ls2, _ = launch_stats(ev2)
+        secondary = {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
+                     "steps": K2, "warmup": W2, "ms_per_step": el2 / K2 * 1e3,
+                     "config": {"workload": "mpc", "lanes_per_gpu": N, "n_rates": 6, "horizon": 5,
+                                "combos_per_lane": 6 ** 5, "predictor": "harmonic"},
+                     "roofline": mpc_roofline(ls2)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(traces, a.seed)
+        if secondary is not None:
+            secondary["cpu_baseline"] = cpu_baseline_mpc(budget_s=5.0)
 
     if rank == 0:
         total_units = units_per_step * K
+        gathering = world > 1 and not a.no_gather and a.workload == "env_random"
         line = {
             "metric": metric, "value": total_units / elapsed, "unit": unit, "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "strong" if a.total_lanes else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": repeats, "repeat_seconds": times,
             "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
-                       "fuse": a.fuse if a.workload == "env_random" else 1,
+                       "fuse": F, "impl": a.impl,
                        "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
                        "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
                        "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
                        "hip_graph": bool(a.graph and world == 1 and a.workload == "env_random"),
                        "auto_reset": True,
-                       "collective": ("all_gather(final obs [8,N] + rewards [fuse,N]) per launch, "
-                                      "overlapped" if world > 1 and not a.no_gather
-                                      and a.workload == "env_random" else "none")},
+                       "collective": (f"1 all_gather_into_tensor per launch of the packed slab [final obs 8xN | "
+                                      f"rewards {F}xN] float32 = {(8 + F) * N * 4} B per rank, overlapped "
+                                      f"with the next launch; backend {backend}; issued "
+                                      f"{gat.n_collectives if gat else 0}x" if gathering else "none")},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
