@@ -75,6 +75,7 @@ SYMBOLS = [
     ("abr_env_get_state", C.c_int, [_P, C.POINTER(StateView)]),
     ("abr_mpc_select", C.c_int, [C.POINTER(MpcConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  C.c_int64, _P]),
+    ("abr_env_step_mpc", C.c_int, [_P, C.POINTER(MpcConfig), _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("abr_mpc_objective_grid", C.c_int, [C.POINTER(MpcConfig), C.c_int32, C.c_int32, C.c_double,
                                          _P, _P, _P, _P, _P]),
 ]

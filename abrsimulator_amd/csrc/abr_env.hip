@@ -135,6 +135,7 @@ struct abr_env {
     size_t workspace_bytes;
     int impl;   // 2 = role-split event-driven kernels (default), 0 = one thread per lane,
                 // 1 = tick-by-tick kernels (cross-check)
+    int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds: latched into p.lane_speeds by the next full reset
     bool speeds_dirty;
 };
@@ -1046,6 +1047,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Layout {
     size_t G, GP, interval_tick, avail_tick;        // table offsets
     size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms, ep_actions;
+    size_t mpc_action;
     size_t total;
     int32_t max_ticks, n_intervals;
 };
@@ -1114,6 +1116,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->bw_hist = o; o = align_up(o + sizeof(double) * V * N, A);
     L->ep_terms = o; o = align_up(o + sizeof(double) * 4 * N, A);
     L->ep_actions = o; o = align_up(o + V * N, A);
+    L->mpc_action = o; o = align_up(o + sizeof(int32_t) * N, A);
     L->total = o;
     return ABR_OK;
 }
@@ -1193,6 +1196,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     p.bw_hist = (double *)(w + L.bw_hist);
     p.ep_qoe_terms = (double *)(w + L.ep_terms);
     p.ep_actions = (uint8_t *)(w + L.ep_actions);
+    e->mpc_action = (int32_t *)(w + L.mpc_action);
 
     hipStream_t st = (hipStream_t)stream;
     hipError_t he;
@@ -1346,6 +1350,8 @@ struct MpcParams {
     double *hist_n, *hist_s;
     const double *br, *sz;
     const uint8_t *mask;
+    int32_t mask_is_done;      // mask[] holds ABR_DONE_* bits: a lane is active iff its byte is 0
+    int32_t neg_to_zero;       // report "no decision" (-1: D13 / D12) as bitrate 0 in action_out
     int32_t *action_out, *flat_out;
     double *J_out;
 };
@@ -1377,12 +1383,14 @@ struct Best { double x; int32_t idx; };
 // BC > 0: the number of rates is a compile-time constant: the two innermost
 // levels are fully unrolled and the innermost level's tables (bl = bitrates,
 // rl = max(0,size,L)/C_hat) live in registers instead of LDS.  BC == 0: generic.
-template <int LVL, int H, int BC>
+// FULL: the lane's horizon is not clipped (heff == H), so no node below the prefix can be a
+// leaf: the per-node `is this the clipped end?` test (and its exec-mask branch) disappears.
+template <int LVL, int H, int BC, bool FULL>
 __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
                                          int r, double q, double v, double rb, double buf,
                                          double br_prev, int32_t flat, Best &best);
 
-template <int LVL, int H, int BC>
+template <int LVL, int H, int BC, bool FULL>
 __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const double *rl,
                                         double q, double v, double rb, double buf,
                                         double br_prev, int32_t flat, Best &best) {
@@ -1410,15 +1418,15 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
         if (g > best.x) { best.x = g; best.idx = flat; }
     } else if constexpr (BC > 0 && LVL >= H - 2) {
 #pragma unroll
-        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC, FULL>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
     } else {
 #pragma unroll 1
-        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC, FULL>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
     }
 }
 
 // inner node (LVL < H - 1)
-template <int LVL, int H, int BC>
+template <int LVL, int H, int BC, bool FULL>
 __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
                                          int r, double q, double v, double rb, double buf,
                                          double br_prev, int32_t flat, Best &best) {
@@ -1428,7 +1436,7 @@ __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, cons
     const double v2 = v + fabs(b - br_prev);                  // :148-149
     const double rb2 = rb + (t.rbt[LVL * B + r] - buf);       // :151-152
     const int32_t f2 = flat * B + r;
-    if (LVL == t.heff - 1) {
+    if (!FULL && LVL == t.heff - 1) {
         // a clipped horizon (D12) ends here: this node is a leaf
         const double x = (q2 - t.wv * v2) - t.wr * rb2;       // = -J, :158-162 (startup term is 0)
         if (x > best.x) { best.x = x; best.idx = f2; }
@@ -1439,7 +1447,7 @@ __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, cons
             const double nb = pymax0(tmp + t.L - wait);                        // :117
             // bitrates[LVL+1][R[LVL+1]] of the child's "previous" digit r (both from chunk LVL+1's ladder)
             const double bp = (LVL + 1 == H - 1 && BC > 0) ? bl[r] : t.brv[(LVL + 1) * B + r];
-            mpc_dfs<LVL + 1, H, BC>(t, bl, rl, q2, v2, rb2, nb, bp, f2, best);
+            mpc_dfs<LVL + 1, H, BC, FULL>(t, bl, rl, q2, v2, rb2, nb, bp, f2, best);
         }
     }
 }
@@ -1496,7 +1504,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     const int pre = tid - li * T;         // prefix id
     const int64_t lane = (int64_t)blockIdx.x * LPB + li;
     const bool valid = (li < LPB) && (lane < p.n_lanes) &&
-                       !(p.mask && !p.mask[lane]);
+                       !(p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0)));
     double *my = tab + (li < LPB ? li : 0) * per_lane;
 
     // ---- phase 1: harmonic predictor, one thread per lane (mpc.py:81-93) ----
@@ -1591,11 +1599,19 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             if (is_leaf) {
                 best.x = (q - t.wv * v) - t.wr * rb; best.idx = flat;
             } else if (D == 2) {
-                if constexpr (H >= 3)
-                    mpc_dfs<2, H, BC>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
+                if constexpr (H >= 3) {
+                    if (t.heff == H)
+                        mpc_dfs<2, H, BC, true>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
+                    else    // clipped horizons (the last H-1 chunks of a video): compact generic code
+                        mpc_dfs<2, H, 0, false>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
+                }
             } else {
-                if constexpr (H >= 2)
-                    mpc_dfs<1, H, BC>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
+                if constexpr (H >= 2) {
+                    if (t.heff == H)
+                        mpc_dfs<1, H, BC, true>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
+                    else
+                        mpc_dfs<1, H, 0, false>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
+                }
             }
         }
     }
@@ -1603,6 +1619,8 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     __syncthreads();
     // ---- phase 4: first arg-max of x = -J over the T prefixes of a lane (ascending prefix =
     //      ascending flat index), then the winning leaf inside the winning group ----
+    if (!valid && pre == 0 && li < LPB && lane < p.n_lanes && p.mask_is_done)
+        p.action_out[lane] = -1;          // a finished lane of the fused rollout takes no decision
     if (valid && pre == 0) {
         double bx = -INFINITY; int32_t bf = 0x7fffffff; bool have = false;
         for (int q2 = 0; q2 < T; q2++) {
@@ -1624,7 +1642,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             for (int i = 1; i < he; i++) lead *= B;
             act = bf / lead;                                   // int(result[0])  mpc.py:186
         }
-        p.action_out[lane] = act;
+        p.action_out[lane] = (p.neg_to_zero && act < 0) ? 0 : act;
         if (p.flat_out) p.flat_out[lane] = have ? bf : -1;
         if (p.J_out) p.J_out[lane] = have ? -bx : NAN;
     }
@@ -1667,6 +1685,31 @@ static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
     launch_mpc_b<H, 0>(p, T, D, st);
 }
 
+static void fill_mpc_params(MpcParams &p, const abr_mpc_config *cfg, int64_t n_lanes) {
+    p.B = cfg->n_rates; p.H = cfg->horizon; p.V = cfg->video_length; p.clip = cfg->clip_horizon;
+    p.L = cfg->chunk_length; p.max_buffer = cfg->max_buffer; p.wv = cfg->variance_weight;
+    p.wr = cfg->rebuffer_weight; p.ws = cfg->startup_weight; p.n_lanes = n_lanes;
+    p.mask = nullptr; p.mask_is_done = 0; p.neg_to_zero = 0;
+    p.flat_out = nullptr; p.J_out = nullptr;
+}
+
+static int launch_mpc_select(const MpcParams &p, hipStream_t st) {
+    const int D = (p.H >= 3) ? 2 : 1;
+    int T = p.B; if (D == 2) T *= p.B;
+    switch (p.H) {
+        case 2: launch_mpc<2>(p, T, D, st); break;
+        case 3: launch_mpc<3>(p, T, D, st); break;
+        case 4: launch_mpc<4>(p, T, D, st); break;
+        case 5: launch_mpc<5>(p, T, D, st); break;
+        case 6: launch_mpc<6>(p, T, D, st); break;
+        case 7: launch_mpc<7>(p, T, D, st); break;
+        case 8: launch_mpc<8>(p, T, D, st); break;
+        default: return fail(ABR_E_INVALID, "horizon %d", p.H);
+    }
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
 extern "C" int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
                               const int32_t *prev_bitrate_dev, const double *buffer_dev,
                               double *hist_n_dev, double *hist_sum_inv_dev,
@@ -1681,27 +1724,58 @@ extern "C" int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_de
         return fail(ABR_E_INVALID, "NULL device pointer");
     if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
     MpcParams p;
-    p.B = cfg->n_rates; p.H = cfg->horizon; p.V = cfg->video_length; p.clip = cfg->clip_horizon;
-    p.L = cfg->chunk_length; p.max_buffer = cfg->max_buffer; p.wv = cfg->variance_weight;
-    p.wr = cfg->rebuffer_weight; p.ws = cfg->startup_weight; p.n_lanes = n_lanes;
+    fill_mpc_params(p, cfg, n_lanes);
     p.chunk = chunk_dev; p.prev = prev_bitrate_dev; p.buffer = buffer_dev;
     p.hist_n = hist_n_dev; p.hist_s = hist_sum_inv_dev; p.br = br_table_dev; p.sz = sz_table_dev;
     p.mask = lane_mask_dev; p.action_out = action_out_dev; p.flat_out = best_flat_out_dev;
     p.J_out = best_J_out_dev;
-    const int D = (p.H >= 3) ? 2 : 1;
-    int T = p.B; if (D == 2) T *= p.B;
+    return launch_mpc_select(p, (hipStream_t)stream);
+}
+
+// The composition the reference leaves unwired (D5/D6): for n_steps decisions,
+// action = MPCBitrateController.next_bitrate() on the lane's own state (mpc.py:181-186 reading
+// chunk_number / previous_bitrate / buffer_level / previous_bandwidths straight from the
+// environment's workspace, history mutation D9 included), then Simulator.run()'s download of
+// that chunk (Simulator.py:155-170).  Two launches per decision, enqueued back to back on
+// `stream`: K3 writes the actions, K1 consumes them; finished lanes are masked by their
+// done bits and "no decision" (empty history at chunk 0, D13) downloads bitrate 0.
+extern "C" int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg,
+                                const double *br_table_dev, const double *sz_table_dev,
+                                int32_t n_steps, float *obs_out_dev, float *reward_out_dev,
+                                uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    int rc = validate_mpc(cfg);
+    if (rc) return rc;
+    if (!br_table_dev || !sz_table_dev) return fail(ABR_E_INVALID, "NULL device pointer");
+    if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
+    if (cfg->n_rates != env->p.n_rates || cfg->video_length != env->p.video_length)
+        return fail(ABR_E_INVALID, "MPC tables are [%d][%d], the environment has video_length %d, n_rates %d",
+                    cfg->video_length, cfg->n_rates, env->p.video_length, env->p.n_rates);
+    if (env->impl == 1) return fail(ABR_E_UNSUPPORTED, "the fused MPC rollout needs the event-driven kernels");
+    const EnvParams &e = env->p;
+    const int64_t N = e.n_lanes;
     hipStream_t st = (hipStream_t)stream;
-    switch (p.H) {
-        case 2: launch_mpc<2>(p, T, D, st); break;
-        case 3: launch_mpc<3>(p, T, D, st); break;
-        case 4: launch_mpc<4>(p, T, D, st); break;
-        case 5: launch_mpc<5>(p, T, D, st); break;
-        case 6: launch_mpc<6>(p, T, D, st); break;
-        case 7: launch_mpc<7>(p, T, D, st); break;
-        case 8: launch_mpc<8>(p, T, D, st); break;
-        default: return fail(ABR_E_INVALID, "horizon %d", p.H);
+    MpcParams p;
+    fill_mpc_params(p, cfg, N);
+    p.chunk = e.chunk_id; p.prev = e.last_action; p.buffer = e.buf;
+    p.hist_n = e.hist_n; p.hist_s = e.hist_s; p.br = br_table_dev; p.sz = sz_table_dev;
+    p.mask = e.done; p.mask_is_done = 1; p.neg_to_zero = 1;
+    for (int32_t s = 0; s < n_steps; s++) {
+        int32_t *act = actions_out_dev ? actions_out_dev + (int64_t)s * N : env->mpc_action;
+        p.action_out = act;
+        rc = launch_mpc_select(p, st);
+        if (rc) return rc;
+        float *obs = obs_out_dev ? obs_out_dev + (int64_t)s * ABR_OBS_DIM * N : nullptr;
+        float *rew = reward_out_dev ? reward_out_dev + (int64_t)s * N : nullptr;
+        uint8_t *dn = done_out_dev ? done_out_dev + (int64_t)s * N : nullptr;
+        if (env->impl == 2)
+            hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(N)), dim3(128), 0, st, env->p, act, obs, rew,
+                               dn, nullptr, 1, 0ull);
+        else
+            hipLaunchKernelGGL(env_jump_kernel<1>, dim3(grid64(N)), dim3(64), 0, st, env->p, act, nullptr,
+                               nullptr, nullptr, obs, rew, dn, nullptr, 1, 0ull);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     return ABR_OK;
 }
 

@@ -188,6 +188,27 @@ class BatchedABREnv:
                    _lib.ptr(out.get("actions")))
         return out
 
+    def step_mpc(self, controller, n_steps: int, out=None, want_obs=True, want_actions=True):
+        """n_steps decisions per lane taken by `controller` (a BatchedMPCController whose
+        tables match this environment) on the device: next_bitrate() on each lane's own
+        state, then the download, with no host work between decisions.  Returns
+        dict(obs[n,OBS_DIM,N], reward[n,N], done[n,N], actions[n,N])."""
+        n = int(n_steps)
+        br, sz = controller._tables()
+        cfg = controller.config()
+        if out is None:
+            out = dict(
+                obs=(torch.empty(n, OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
+                     if want_obs else None),
+                reward=torch.empty(n, self.n_lanes, dtype=torch.float32, device=self.device),
+                done=torch.empty(n, self.n_lanes, dtype=torch.uint8, device=self.device),
+                actions=(torch.empty(n, self.n_lanes, dtype=torch.int32, device=self.device)
+                         if want_actions else None))
+        self._call(self.lib.abr_env_step_mpc, self._h, C.byref(cfg), _lib.ptr(br), _lib.ptr(sz), n,
+                   _lib.ptr(out.get("obs")), _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")),
+                   _lib.ptr(out.get("actions")))
+        return out
+
     # -- exact state -------------------------------------------------------
     def observe_f64(self):
         """dict of float64 [N] tensors: everything the reference's run() frame holds

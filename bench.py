@@ -275,18 +275,23 @@ def main():
         return player, ctl, player.hist_n.clone(), player.hist_sum_inv.clone()
 
     def mpc_runner(player, ctl, hist_n0, hist_s0, events, drive_env):
+        mpc_out = dict(obs=torch.empty(1, OBS_DIM, N, dtype=torch.float32, device=dev),
+                       reward=torch.empty(1, N, dtype=torch.float32, device=dev),
+                       done=torch.empty(1, N, dtype=torch.uint8, device=dev), actions=None)
+
         def run(n_steps, timed):
             for _ in range(n_steps):
                 if not drive_env:
                     player.hist_n.copy_(hist_n0); player.hist_sum_inv.copy_(hist_s0)
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
-                act = ctl.next_bitrate()
+                if drive_env:
+                    env.step_mpc(ctl, 1, out=mpc_out)       # K3 + K1 on the device, no host glue
+                else:
+                    ctl.next_bitrate()
                 if timed:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
                     events.append((e0, e1, 1))
-                if drive_env:
-                    env.step(torch.clamp(act, min=0))
         return run
 
     if a.workload == "env_random":

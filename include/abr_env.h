@@ -250,6 +250,29 @@ int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
                    int32_t *best_flat_out_dev, double *best_J_out_dev, int64_t n_lanes,
                    void *stream);
 
+/*
+ * MPC-driven rollout, fused on the device: for n_steps decisions, each lane's action is
+ * MPCBitrateController.next_bitrate() (mpc.py:181-186) evaluated on the lane's OWN
+ * environment state -- chunk_number = chunk_id, previous_bitrate = previous_bitrates[-1],
+ * buffer_level, and previous_bandwidths as the environment's (len, sum of reciprocals)
+ * summary, which the predictor grows by `horizon` entries per call exactly as the reference
+ * mutates the shared list (mpc.py:92, D9) -- followed by the download of that chunk
+ * (Simulator.py:155-170; abr_env_step).  This is the wiring the reference leaves open
+ * (get_next_bitrate(...) at Simulator.py:155 vs next_bitrate() at mpc.py:181, D5/D6); no host
+ * round trip or host-side tensor work happens between decisions.
+ *  br_table_dev/sz_table_dev: [video_length][n_rates] as for abr_mpc_select; cfg->n_rates and
+ *  cfg->video_length must equal the environment's.
+ *  Lanes whose done bits are set take no decision (action -1) and stay frozen.  A lane the
+ *  reference would raise on (empty history at chunk 0: ZeroDivisionError, D13; horizon past
+ *  the video end without clip_horizon, D12) downloads bitrate 0 and keeps its history.
+ *  Outputs (all nullable): obs [n_steps][ABR_OBS_DIM][n_lanes], reward/done/actions
+ *  [n_steps][n_lanes], as abr_env_step_random.  Event-driven kernels only (impl 0 or 2).
+ */
+int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg, const double *br_table_dev,
+                     const double *sz_table_dev, int32_t n_steps, float *obs_out_dev,
+                     float *reward_out_dev, uint8_t *done_out_dev, int32_t *actions_out_dev,
+                     void *stream);
+
 /* Diagnostic: the full objective grid of ONE lane, J_out_dev float64
  * [n_rates^horizon], given explicit predictions pred_dev[horizon]. */
 int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk, int32_t prev_bitrate,

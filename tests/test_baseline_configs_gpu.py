@@ -117,8 +117,9 @@ def test_shard_shape_131072_lanes_equals_unsharded_slice_and_oracle(oracle):
 # ---------------------------------------------------------------------------------------------
 # configs[4]: mixed trace lengths x MPC-driven rollout
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["fused", "host_loop"])
 @pytest.mark.parametrize("wv,wr", [(1.0, 4.3), (0.5, 0.3)])     # the bench weights; a mix of all six rates
-def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr):
+def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr, path):
     import abrsimulator_amd as A
     from abrsimulator_amd.sharding import lane_assignment
     N, H = 512, 5
@@ -136,12 +137,24 @@ def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr):
     mpd = A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(list(b), list(s)) for b, s in zip(br, sz)])
     player = A.EnvPlayer(env, mpd=mpd, qoe=A.QOEMetric(wr, wv, 0.0))
     ctl = A.BatchedMPCController(player, horizon=H, clip_horizon=True)
-    gpu_actions = []
-    for s in range(V):
-        a = torch.clamp(ctl.next_bitrate(), min=0)          # D13 at chunk 0: "no decision" -> rate 0
-        gpu_actions.append(a.cpu().numpy().copy())
-        env.step(a)
-    gpu_actions = np.stack(gpu_actions, 1)
+    if path == "fused":
+        # abr_env_step_mpc: select -> step for all V decisions on the device
+        out = env.step_mpc(ctl, V)
+        gpu_actions = out["actions"].cpu().numpy().T
+        d = out["done"].cpu().numpy()
+        assert (d[:-1] == 0).all() and (d[-1] == 1).all()
+        # a second call on the finished lanes takes no decision and changes nothing
+        before = env.observe_f64()["global_time"].clone()
+        again = env.step_mpc(ctl, 2)
+        assert (again["actions"].cpu().numpy() == -1).all() and (again["done"].cpu().numpy() == 1).all()
+        assert torch.equal(env.observe_f64()["global_time"], before)
+    else:
+        gpu_actions = []
+        for s in range(V):
+            a = torch.clamp(ctl.next_bitrate(), min=0)      # D13 at chunk 0: "no decision" -> rate 0
+            gpu_actions.append(a.cpu().numpy().copy())
+            env.step(a)
+        gpu_actions = np.stack(gpu_actions, 1)
     ecfg = oracle.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
     mcfg = oracle.mpc_cfg(6, H, V, L, MAX_BUFFER, wv, wr, 0.0)
     steps, bw, acts, fin = oracle.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid, off, threads=8)
