@@ -1385,15 +1385,22 @@ struct Best { double x; int32_t idx; };
 // rl = max(0,size,L)/C_hat) live in registers instead of LDS.  BC == 0: generic.
 // FULL: the lane's horizon is not clipped (heff == H), so no node below the prefix can be a
 // leaf: the per-node `is this the clipped end?` test (and its exec-mask branch) disappears.
-template <int LVL, int H, int BC, bool FULL>
+// WVM: how variance_weight enters a leaf (mpc.py:158): 0 = multiply; 1 = the weight is exactly
+// 1.0, and x * 1.0 is x bit for bit, so the multiplication is dropped; 2 = the weight is
+// exactly 0.0 (mpc_test.py's QOEMetric), 0.0 * v is +0.0 for the finite non-negative v that
+// occur and q - 0.0 is q, so the whole variance term is dropped.
+template <int LVL, int H, int BC, bool FULL, int WVM>
 __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
                                          int r, double q, double v, double rb, double buf,
-                                         double br_prev, int32_t flat, Best &best);
+                                         double br_prev, int pd, int32_t flat, Best &best);
 
-template <int LVL, int H, int BC, bool FULL>
+template <int LVL, int H, int BC, bool FULL, int WVM>
 __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const double *rl,
                                         double q, double v, double rb, double buf,
-                                        double br_prev, int32_t flat, Best &best) {
+                                        double br_prev, int pd, int32_t flat, Best &best) {
+    // pd: the digit br_prev belongs to when the caller knows it at compile time (unrolled
+    // levels), else -1.  The same digit one level down means |b - br_prev| is |b - b| = +0.0
+    // and v + 0.0 is v (v >= +0.0): those two operations are skipped, bit for bit.
     const int B = BC ? BC : t.B;
     if constexpr (LVL == H - 1) {
         // innermost level: only the group maximum is tracked (v_max_f64 per leaf instead of
@@ -1403,7 +1410,11 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
 #pragma unroll
             for (int r = 0; r < BC; r++) {
                 const double b = bl[r];
-                const double x = ((q + b) - t.wv * (v + fabs(b - br_prev))) - t.wr * (rb + (rl[r] - buf));
+                double a = q + b;                                                    // :146
+                const double vv = (r == pd) ? v : v + fabs(b - br_prev);            // :148-149
+                if (WVM == 0) a = a - t.wv * vv;                                     // :158
+                if (WVM == 1) a = a - vv;
+                const double x = a - t.wr * (rb + (rl[r] - buf));                    // :151-152,:159
                 g = fmax(g, x);
             }
         } else {
@@ -1418,22 +1429,22 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
         if (g > best.x) { best.x = g; best.idx = flat; }
     } else if constexpr (BC > 0 && LVL >= H - 2) {
 #pragma unroll
-        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC, FULL>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
     } else {
 #pragma unroll 1
-        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC, FULL>(t, bl, rl, r, q, v, rb, buf, br_prev, flat, best);
+        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
     }
 }
 
 // inner node (LVL < H - 1)
-template <int LVL, int H, int BC, bool FULL>
+template <int LVL, int H, int BC, bool FULL, int WVM>
 __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, const double *rl,
                                          int r, double q, double v, double rb, double buf,
-                                         double br_prev, int32_t flat, Best &best) {
+                                         double br_prev, int pd, int32_t flat, Best &best) {
     const int B = BC ? BC : t.B;
     const double b = t.brv[LVL * B + r];
     const double q2 = q + b;                                  // :146
-    const double v2 = v + fabs(b - br_prev);                  // :148-149
+    const double v2 = (r == pd) ? v : v + fabs(b - br_prev);  // :148-149
     const double rb2 = rb + (t.rbt[LVL * B + r] - buf);       // :151-152
     const int32_t f2 = flat * B + r;
     if (!FULL && LVL == t.heff - 1) {
@@ -1447,7 +1458,10 @@ __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, cons
             const double nb = pymax0(tmp + t.L - wait);                        // :117
             // bitrates[LVL+1][R[LVL+1]] of the child's "previous" digit r (both from chunk LVL+1's ladder)
             const double bp = (LVL + 1 == H - 1 && BC > 0) ? bl[r] : t.brv[(LVL + 1) * B + r];
-            mpc_dfs<LVL + 1, H, BC, FULL>(t, bl, rl, q2, v2, rb2, nb, bp, f2, best);
+            // the child level sees this node's digit as its "previous" one; only worth telling
+            // it when this level is unrolled (r is then a compile-time constant)
+            mpc_dfs<LVL + 1, H, BC, FULL, WVM>(t, bl, rl, q2, v2, rb2, nb, bp,
+                                               (BC > 0 && LVL >= H - 2) ? r : -1, f2, best);
         }
     }
 }
@@ -1485,7 +1499,7 @@ constexpr int kMpcLanesPerBlock = 16;
 
 // Threads of a block: (lane-in-block, prefix) pairs.  D = number of leading
 // levels fixed per thread (2 when H >= 3, else 1) -> T = B^D threads per lane.
-template <int H, int BC>
+template <int H, int BC, int WVM>
 __global__ __launch_bounds__(256, 4)
 void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     extern __shared__ double lds[];
@@ -1601,16 +1615,16 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             } else if (D == 2) {
                 if constexpr (H >= 3) {
                     if (t.heff == H)
-                        mpc_dfs<2, H, BC, true>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
+                        mpc_dfs<2, H, BC, true, WVM>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], -1, flat, best);
                     else    // clipped horizons (the last H-1 chunks of a video): compact generic code
-                        mpc_dfs<2, H, 0, false>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], flat, best);
+                        mpc_dfs<2, H, 0, false, 0>(t, bl, rl, q, v, rb, buf, t.brv[2 * B + prev_r], -1, flat, best);
                 }
             } else {
                 if constexpr (H >= 2) {
                     if (t.heff == H)
-                        mpc_dfs<1, H, BC, true>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
+                        mpc_dfs<1, H, BC, true, WVM>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], -1, flat, best);
                     else
-                        mpc_dfs<1, H, 0, false>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], flat, best);
+                        mpc_dfs<1, H, 0, false, 0>(t, bl, rl, q, v, rb, buf, t.brv[1 * B + prev_r], -1, flat, best);
                 }
             }
         }
@@ -1660,7 +1674,7 @@ static int validate_mpc(const abr_mpc_config *c) {
     return ABR_OK;
 }
 
-template <int H, int BC>
+template <int H, int BC, int WVM>
 static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
     // lanes per workgroup: as many as fit 256 threads (4 waves).  Measured on MI355X at B=6,H=5
     // (T=36): 7 lanes/WG 319 us, 16 lanes/WG (9 waves) 481 us, 3 lanes/WG 365 us per 65 536 lanes.
@@ -1672,17 +1686,21 @@ static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
     const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);
     const size_t lds = lpb * per_lane + (size_t)lpb * T * (sizeof(double) + sizeof(int32_t));
     const unsigned grid = (unsigned)((p.n_lanes + lpb - 1) / lpb);
-    hipLaunchKernelGGL((mpc_select_kernel<H, BC>), dim3(grid), dim3(threads), lds, st, p, T, D, lpb);
+    hipLaunchKernelGGL((mpc_select_kernel<H, BC, WVM>), dim3(grid), dim3(threads), lds, st, p, T, D, lpb);
 }
 
 // compile-time rate count for the common ladders (6 and 4 rates) up to horizon 6
 template <int H>
 static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
     if constexpr (H <= 6) {
-        if (p.B == 6) { launch_mpc_b<H, 6>(p, T, D, st); return; }
-        if (p.B == 4) { launch_mpc_b<H, 4>(p, T, D, st); return; }
+        // exact-weight specialisations (see WVM above) for the six-rate ladder
+        if (p.B == 6 && p.wv == 1.0) { launch_mpc_b<H, 6, 1>(p, T, D, st); return; }
+        if (p.B == 6 && p.wv == 0.0) { launch_mpc_b<H, 6, 2>(p, T, D, st); return; }
+        if (p.B == 6) { launch_mpc_b<H, 6, 0>(p, T, D, st); return; }
+        if (p.B == 4 && p.wv == 0.0) { launch_mpc_b<H, 4, 2>(p, T, D, st); return; }
+        if (p.B == 4) { launch_mpc_b<H, 4, 0>(p, T, D, st); return; }
     }
-    launch_mpc_b<H, 0>(p, T, D, st);
+    launch_mpc_b<H, 0, 0>(p, T, D, st);
 }
 
 static void fill_mpc_params(MpcParams &p, const abr_mpc_config *cfg, int64_t n_lanes) {

@@ -409,10 +409,12 @@ def main():
 
     def mpc_roofline(launch_s):
         # K3 is fp64-VALU-bound.  Executed work with prefix sharing: 7 776 leaves x
-        # 9 flop + 1 554 inner nodes x 13 flop = 90.2 kflop per lane decision (the reference's
+        # 9 flop + 1 554 inner nodes x 13 flop = 90.2 kflop per lane decision (82.4 with the x1.0
+        # weight dropped; the reference's
         # from-scratch formulation is 99 flop x 7 776 combos = 770 kflop).  No FMA may
         # be used (-ffp-contract=off is the parity contract), so 50 % of the FMA peak is the ceiling.
-        flops = N * (7776 * 9.0 + 1554 * 13.0)
+        # (variance_weight is exactly 1.0 here, so the kernel drops that multiplication: 8 per leaf)
+        flops = N * (7776 * 8.0 - 1296 * 2.0 + 1554 * 13.0)   # 1 296 leaves repeat their parent digit: variance term is +0.0, skipped
         roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5,6>",
                     achieved=flops / launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                     traffic=None, avg_launch_us=launch_s * 1e6,
