@@ -49,6 +49,11 @@ class MpcConfig(C.Structure):
                 ("rebuffer_weight", C.c_double), ("startup_weight", C.c_double)]
 
 
+class MpcOptions(C.Structure):
+    _fields_ = [("predictor", C.c_int32), ("utility", C.c_int32), ("hist_dev", C.c_void_p),
+                ("hist_stride", C.c_int64), ("hist_len_dev", C.c_void_p)]
+
+
 class StateView(C.Structure):
     _fields_ = [("n_lanes", C.c_int64), ("chunk_id", C.c_void_p), ("last_bitrate", C.c_void_p),
                 ("buffer_level", C.c_void_p), ("hist_n", C.c_void_p), ("hist_sum_inv", C.c_void_p),
@@ -75,7 +80,10 @@ SYMBOLS = [
     ("abr_env_get_state", C.c_int, [_P, C.POINTER(StateView)]),
     ("abr_mpc_select", C.c_int, [C.POINTER(MpcConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  C.c_int64, _P]),
+    ("abr_mpc_select_opt", C.c_int, [C.POINTER(MpcConfig), C.POINTER(MpcOptions), _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, C.c_int64, _P]),
     ("abr_env_step_mpc", C.c_int, [_P, C.POINTER(MpcConfig), _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    ("abr_debug_chain", C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
     ("abr_mpc_objective_grid", C.c_int, [C.POINTER(MpcConfig), C.c_int32, C.c_int32, C.c_double,
                                          _P, _P, _P, _P, _P]),
 ]

@@ -1349,6 +1349,12 @@ struct MpcParams {
     const double *buffer;
     double *hist_n, *hist_s;
     const double *br, *sz;
+    // f4 (parity unpinned, see include/abr_env.h: abr_mpc_options)
+    int32_t predictor;         // 0 harmonic (mpc.py:81-93), 1 exponential smoothing (mpc.py:72-79)
+    int32_t utility;           // 0 identity (mpc.py:95-97), 1 log(bitrate / top bitrate) (mpc.py:99-102)
+    const double *hist;        // predictor 1: previous_bandwidths, entry t of lane i at hist[t * hist_stride + i]
+    int64_t hist_stride;
+    const int32_t *hist_len;   // predictor 1: len(previous_bandwidths) per lane
     const uint8_t *mask;
     int32_t mask_is_done;      // mask[] holds ABR_DONE_* bits: a lane is active iff its byte is 0
     int32_t neg_to_zero;       // report "no decision" (-1: D13 / D12) as bitrate 0 in action_out
@@ -1535,7 +1541,31 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         const bool prev_ok = (pv >= -B) && (pv < B);
         if (pv < 0) pv += B;
         prev_s[li] = prev_ok ? pv : 0;
-        if (!(n > 0.0) || !(S > 0.0) || c < 0 || !prev_ok) {
+        if (p.predictor == 1) {
+            // method="expsmoothing" (mpc.py:72-79): SimpleExpSmoothing(data).fit(0.5), then the
+            // H out-of-sample forecasts -- all equal to the last smoothed level.  statsmodels is
+            // not available to pin this against (PARITY UNPINNED); the rule implemented is the
+            // documented one: smoothing level 0.5, initial level = the least-squares optimum of
+            // the one-step-ahead errors (what fit()'s default `estimated` initialisation
+            // approximates numerically), in closed form.  With l(t-1) = a + b*l0 the level before
+            // observation y(t):  l0 = sum b (y - a) / sum b^2.  The history is NOT grown (the
+            // reference's branch returns before the append of mpc.py:92).
+            const int32_t hl = p.hist_len ? p.hist_len[lane] : 0;
+            if (hl <= 0 || c < 0 || !prev_ok) he = 0;
+            else {
+                double a = 0.0, b = 1.0, num = 0.0, den = 0.0;
+                for (int32_t tt = 0; tt < hl; tt++) {
+                    const double y = p.hist[(int64_t)tt * p.hist_stride + lane];
+                    num = num + b * (y - a);
+                    den = den + b * b;
+                    a = 0.5 * y + 0.5 * a;
+                    b = 0.5 * b;
+                }
+                const double level = a + b * (num / den);
+                if (!(level > 0.0)) he = 0;
+                else for (int i = 0; i < H; i++) my[3 * HB + i] = level;
+            }
+        } else if (!(n > 0.0) || !(S > 0.0) || c < 0 || !prev_ok) {
             // D13: empty / zero throughput history -- the reference raises ZeroDivisionError
             // (mpc.py:88,90); likewise an out-of-range previous_bitrate (IndexError).  Defined
             // here as "no decision": history untouched, action -1.
@@ -1564,7 +1594,10 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
                 double m = 0.0;
                 if (s_i > m) m = s_i;
                 if (p.L > m) m = p.L;                      // max(0, size, chunk_length)
-                my[e] = p.br[(int64_t)(c + i) * B + r];
+                const double bre = p.br[(int64_t)(c + i) * B + r];
+                // utility 1: log_bitrate_utility with the arity its call sites need (mpc.py:99-102,
+                // :146-149): u = log(bitrate / top bitrate of that chunk).  PARITY UNPINNED.
+                my[e] = p.utility == 1 ? log(bre / p.br[(int64_t)(c + i) * B + (B - 1)]) : bre;
                 my[HB + e] = m / pr;
                 my[2 * HB + e] = p.sz[(int64_t)c * B + r] / pr;
             }
@@ -1708,6 +1741,7 @@ static void fill_mpc_params(MpcParams &p, const abr_mpc_config *cfg, int64_t n_l
     p.L = cfg->chunk_length; p.max_buffer = cfg->max_buffer; p.wv = cfg->variance_weight;
     p.wr = cfg->rebuffer_weight; p.ws = cfg->startup_weight; p.n_lanes = n_lanes;
     p.mask = nullptr; p.mask_is_done = 0; p.neg_to_zero = 0;
+    p.predictor = 0; p.utility = 0; p.hist = nullptr; p.hist_stride = 0; p.hist_len = nullptr;
     p.flat_out = nullptr; p.J_out = nullptr;
 }
 
@@ -1743,6 +1777,43 @@ extern "C" int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_de
     if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
     MpcParams p;
     fill_mpc_params(p, cfg, n_lanes);
+    p.chunk = chunk_dev; p.prev = prev_bitrate_dev; p.buffer = buffer_dev;
+    p.hist_n = hist_n_dev; p.hist_s = hist_sum_inv_dev; p.br = br_table_dev; p.sz = sz_table_dev;
+    p.mask = lane_mask_dev; p.action_out = action_out_dev; p.flat_out = best_flat_out_dev;
+    p.J_out = best_J_out_dev;
+    return launch_mpc_select(p, (hipStream_t)stream);
+}
+
+static int apply_mpc_options(MpcParams &p, const abr_mpc_options *opt) {
+    if (!opt) return ABR_OK;
+    if (opt->predictor != ABR_PREDICT_HARMONIC && opt->predictor != ABR_PREDICT_EXPSMOOTHING)
+        return fail(ABR_E_INVALID, "predictor must be ABR_PREDICT_HARMONIC or ABR_PREDICT_EXPSMOOTHING");
+    if (opt->utility != ABR_UTILITY_IDENTITY && opt->utility != ABR_UTILITY_LOG)
+        return fail(ABR_E_INVALID, "utility must be ABR_UTILITY_IDENTITY or ABR_UTILITY_LOG");
+    if (opt->predictor == ABR_PREDICT_EXPSMOOTHING && (!opt->hist_dev || !opt->hist_len_dev || opt->hist_stride < 1))
+        return fail(ABR_E_INVALID, "exponential smoothing needs the history itself: hist_dev, hist_stride, hist_len_dev");
+    p.predictor = opt->predictor; p.utility = opt->utility;
+    p.hist = opt->hist_dev; p.hist_stride = opt->hist_stride; p.hist_len = opt->hist_len_dev;
+    return ABR_OK;
+}
+
+extern "C" int abr_mpc_select_opt(const abr_mpc_config *cfg, const abr_mpc_options *opt,
+                                  const int32_t *chunk_dev, const int32_t *prev_bitrate_dev,
+                                  const double *buffer_dev, double *hist_n_dev,
+                                  double *hist_sum_inv_dev, const double *br_table_dev,
+                                  const double *sz_table_dev, const uint8_t *lane_mask_dev,
+                                  int32_t *action_out_dev, int32_t *best_flat_out_dev,
+                                  double *best_J_out_dev, int64_t n_lanes, void *stream) {
+    int rc = validate_mpc(cfg);
+    if (rc) return rc;
+    if (!chunk_dev || !prev_bitrate_dev || !buffer_dev || !hist_n_dev || !hist_sum_inv_dev ||
+        !br_table_dev || !sz_table_dev || !action_out_dev)
+        return fail(ABR_E_INVALID, "NULL device pointer");
+    if (n_lanes < 1) return fail(ABR_E_INVALID, "n_lanes must be >= 1");
+    MpcParams p;
+    fill_mpc_params(p, cfg, n_lanes);
+    rc = apply_mpc_options(p, opt);
+    if (rc) return rc;
     p.chunk = chunk_dev; p.prev = prev_bitrate_dev; p.buffer = buffer_dev;
     p.hist_n = hist_n_dev; p.hist_s = hist_sum_inv_dev; p.br = br_table_dev; p.sz = sz_table_dev;
     p.mask = lane_mask_dev; p.action_out = action_out_dev; p.flat_out = best_flat_out_dev;
@@ -1795,6 +1866,51 @@ extern "C" int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg,
         HIP_TRY(hipGetLastError());
     }
     return ABR_OK;
+}
+
+// Diagnostic: the exact chain (abr_exact_jump.h) on arbitrary inputs, one case per thread, so
+// tests can compare the DEVICE build of the jump arithmetic -- v_rcp_f64 estimate, saturating
+// convert, and (with a biased estimate) the out-of-line exact search -- with the naive loop.
+template <int STOP, int BIAS>
+__global__ void chain_debug_kernel(const double *__restrict__ x0, const double *__restrict__ c,
+                                   const double *__restrict__ thr, const int32_t *__restrict__ n,
+                                   int64_t count, double *__restrict__ x_out,
+                                   int32_t *__restrict__ a_out, uint8_t *__restrict__ hit_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double x = x0[i];
+    int32_t a = 0;
+    const bool hit = abrx::chain<STOP, BIAS>(x, c[i], thr[i], n[i], a);
+    x_out[i] = x; a_out[i] = a; hit_out[i] = hit ? 1 : 0;
+}
+
+template <int STOP>
+static int launch_chain_debug(int32_t bias, const double *x0, const double *c, const double *thr,
+                              const int32_t *n, int64_t count, double *x_out, int32_t *a_out,
+                              uint8_t *hit_out, hipStream_t st) {
+    const dim3 g((unsigned)((count + 63) / 64)), b(64);
+    if (bias == 0) hipLaunchKernelGGL((chain_debug_kernel<STOP, 0>), g, b, 0, st, x0, c, thr, n, count, x_out, a_out, hit_out);
+    else if (bias == 4) hipLaunchKernelGGL((chain_debug_kernel<STOP, 4>), g, b, 0, st, x0, c, thr, n, count, x_out, a_out, hit_out);
+    else if (bias == -4) hipLaunchKernelGGL((chain_debug_kernel<STOP, -4>), g, b, 0, st, x0, c, thr, n, count, x_out, a_out, hit_out);
+    else return fail(ABR_E_INVALID, "estimate_bias must be 0, 4 or -4");
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+extern "C" int abr_debug_chain(int32_t stop_kind, int32_t estimate_bias, const double *x0_dev,
+                               const double *c_dev, const double *thr_dev, const int32_t *n_dev,
+                               int64_t count, double *x_out_dev, int32_t *a_out_dev,
+                               uint8_t *hit_out_dev, void *stream) {
+    if (!x0_dev || !c_dev || !thr_dev || !n_dev || !x_out_dev || !a_out_dev || !hit_out_dev)
+        return fail(ABR_E_INVALID, "NULL device pointer");
+    if (count < 1) return fail(ABR_E_INVALID, "count must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    switch (stop_kind) {
+        case abrx::STOP_GE: return launch_chain_debug<abrx::STOP_GE>(estimate_bias, x0_dev, c_dev, thr_dev, n_dev, count, x_out_dev, a_out_dev, hit_out_dev, st);
+        case abrx::STOP_LE: return launch_chain_debug<abrx::STOP_LE>(estimate_bias, x0_dev, c_dev, thr_dev, n_dev, count, x_out_dev, a_out_dev, hit_out_dev, st);
+        case abrx::STOP_LT: return launch_chain_debug<abrx::STOP_LT>(estimate_bias, x0_dev, c_dev, thr_dev, n_dev, count, x_out_dev, a_out_dev, hit_out_dev, st);
+        default: return fail(ABR_E_INVALID, "stop_kind must be 0 (>=), 1 (<=) or 2 (<)");
+    }
 }
 
 // Diagnostic: every combo evaluated from scratch by its own thread, literally as

@@ -138,7 +138,9 @@ int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t
 // predicate.  cs.inb counts the real in-binade additions just performed (only the
 // tie case needs one before it may jump); a caller that changes c resets it to 0.
 // Straight-line selects on purpose: this is the body of the GPU hot loop.
-template <int STOP>
+// BIAS (tests only) is added to the jump-length estimate: a non-zero value breaks the
+// four-candidate bracket on purpose, so that the out-of-line exact search is exercised.
+template <int STOP, int BIAS = 0>
 ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit_out) {
 #ifdef ABR_SEGMENT_HOOK
     ABR_SEGMENT_HOOK(STOP);              // host-side analysis builds count segments per chain kind
@@ -180,6 +182,7 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
         const int32_t room = can ? n : 0;
         // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0).
         int32_t m0 = sat_i32(gap * rcp_est(dm));
+        if (BIAS != 0) m0 = (m0 < 0x7fffff00 && m0 > -0x7fffff00) ? m0 + BIAS : m0;
         m0 = (m0 > 0) ? m0 : 0;
         m0 = (m0 < room) ? m0 : room;
         // Exact settlement (x + m*d is exact while it stays inside the binade).  The
@@ -230,13 +233,13 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
 // stopping one).  c > 0 requires STOP_GE; c < 0 requires STOP_LE or STOP_LT.
 // Bit-identical to the naive loop for every finite input (fuzzed in
 // tests/test_exact_jump.py).
-template <int STOP>
+template <int STOP, int BIAS = 0>
 ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out) {
     ChainState cs;
     cs.x = x_io; cs.d = 0.0; cs.inb = 0;
     int32_t a = 0;
     bool hit = false;
-    while (a < n && !hit) a += chain_segment<STOP>(cs, c, thr, n - a, hit);
+    while (a < n && !hit) a += chain_segment<STOP, BIAS>(cs, c, thr, n - a, hit);
     x_io = cs.x;
     a_out = a;
     return hit;

@@ -28,12 +28,22 @@ class BatchedMPCController:
     the behaviour where the reference raises IndexError (D12).
     """
 
+    METHODS = {"harmonic": 0, "expsmoothing": 1}
+    UTILITIES = {"identity": 0, "log": 1}
+
     def __init__(self, player=None, bitrate_utility=None, horizon=None, clip_horizon=True,
-                 device="cuda"):
+                 device="cuda", *, method="harmonic", utility="identity"):
         self.lib = _lib.lib()
         self.device = torch.device(device)
         self.horizon = 3 if horizon is None else int(horizon)
         self.clip_horizon = bool(clip_horizon)
+        # the reference's alternative predictor / utility (mpc.py:72-79, :99-102): PARITY UNPINNED,
+        # see include/abr_env.h: abr_mpc_options.  method="expsmoothing" needs the throughput
+        # history itself: chunk-info fields `previous_bandwidths` f64[T, N] (entry t of lane i)
+        # and `history_length` i32[N]  (EnvPlayer provides both).
+        if method not in self.METHODS or utility not in self.UTILITIES:
+            raise ValueError("method is 'harmonic' or 'expsmoothing'; utility is 'identity' or 'log'")
+        self.method, self.utility = method, utility
         self.player = None
         self._tables_for = None
         if player is not None:
@@ -93,9 +103,22 @@ class BatchedMPCController:
                       (ci.hist_sum_inv, torch.float64)):
             if t.dtype != dt or t.device.type != "cuda":
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
+        opt = None
+        if self.method != "harmonic" or self.utility != "identity":
+            opt = _lib.MpcOptions()
+            opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
+            if self.method == "expsmoothing":
+                hist, hlen = ci.previous_bandwidths, ci.history_length
+                if hist.dtype != torch.float64 or hist.dim() != 2 or hist.shape[1] != N or hist.stride(1) != 1:
+                    raise TypeError("previous_bandwidths must be float64 [T, N] with unit lane stride")
+                if hlen.dtype != torch.int32 or int(hlen.max()) > hist.shape[0]:
+                    raise TypeError("history_length must be int32 [N], at most T")
+                opt.hist_dev, opt.hist_stride = hist.data_ptr(), hist.stride(0)
+                opt.hist_len_dev = hlen.data_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.abr_mpc_select(
-                C.byref(cfg), _lib.ptr(ci.chunk_number), _lib.ptr(ci.previous_bitrate),
+            _lib.check(self.lib.abr_mpc_select_opt(
+                C.byref(cfg), C.byref(opt) if opt is not None else None,
+                _lib.ptr(ci.chunk_number), _lib.ptr(ci.previous_bitrate),
                 _lib.ptr(ci.buffer_level), _lib.ptr(ci.hist_n), _lib.ptr(ci.hist_sum_inv),
                 _lib.ptr(br), _lib.ptr(sz), _lib.ptr(mask), _lib.ptr(action), _lib.ptr(flat),
                 _lib.ptr(J), N, _lib.current_stream(self.device)))
@@ -143,4 +166,8 @@ class EnvPlayer:
         ci.chunk_number, ci.previous_bitrate = self.chunk_id, self.last_bitrate
         ci.buffer_level, ci.hist_n, ci.hist_sum_inv = self.buffer_level, self.hist_n, self.hist_sum_inv
         ci.mask = (self.done == 0).to(torch.uint8)
+        # the list itself, for predictors that need more than its harmonic summary (f4):
+        # previous_bandwidths[t, i] for t < chunk_id[i]
+        ci.previous_bandwidths = self.env.history()[1]
+        ci.history_length = self.chunk_id
         return ci

@@ -251,6 +251,45 @@ int abr_mpc_select(const abr_mpc_config *cfg, const int32_t *chunk_dev,
                    void *stream);
 
 /*
+ * The reference's alternative predictor and utility.  PARITY UNPINNED:
+ * the predictor needs statsmodels (mpc.py:4,74), which is not installable here, and no test
+ * of the reference touches either; what is implemented is the documented rule below, checked
+ * for self-consistency only.
+ *  ABR_PREDICT_EXPSMOOTHING  predict_throughput(..., method="expsmoothing") (mpc.py:72-79):
+ *      SimpleExpSmoothing(history).fit(0.5) and its `horizon` out-of-sample forecasts, i.e.
+ *      the last smoothed level repeated: level(t) = 0.5*y(t) + 0.5*level(t-1), with the
+ *      initial level chosen to minimise the sum of squared one-step-ahead errors (closed
+ *      form; statsmodels' default `estimated` initialisation finds it numerically).  Needs
+ *      the throughput history itself: entry t of lane i at hist_dev[t * hist_stride + i],
+ *      hist_len_dev[i] entries (for an environment: abr_env_state_view.bw_hist with stride
+ *      n_lanes and chunk_id as the length).  Unlike the harmonic branch it does not grow the
+ *      history (no D9) and ignores hist_n / hist_sum_inv.
+ *  ABR_UTILITY_LOG  log_bitrate_utility (mpc.py:99-102) with the arity its call sites need:
+ *      u = log(bitrate / highest bitrate of that chunk) in place of the identity utility in
+ *      video_quality and quality_variance (mpc.py:146-149).
+ */
+#define ABR_PREDICT_HARMONIC 0
+#define ABR_PREDICT_EXPSMOOTHING 1
+#define ABR_UTILITY_IDENTITY 0
+#define ABR_UTILITY_LOG 1
+typedef struct abr_mpc_options {
+    int32_t predictor;            /* ABR_PREDICT_* */
+    int32_t utility;              /* ABR_UTILITY_* */
+    const double *hist_dev;       /* ABR_PREDICT_EXPSMOOTHING only */
+    int64_t hist_stride;
+    const int32_t *hist_len_dev;
+} abr_mpc_options;
+
+/* abr_mpc_select with options; opt == NULL is abr_mpc_select. */
+int abr_mpc_select_opt(const abr_mpc_config *cfg, const abr_mpc_options *opt,
+                       const int32_t *chunk_dev, const int32_t *prev_bitrate_dev,
+                       const double *buffer_dev, double *hist_n_dev, double *hist_sum_inv_dev,
+                       const double *br_table_dev, const double *sz_table_dev,
+                       const uint8_t *lane_mask_dev, int32_t *action_out_dev,
+                       int32_t *best_flat_out_dev, double *best_J_out_dev, int64_t n_lanes,
+                       void *stream);
+
+/*
  * MPC-driven rollout, fused on the device: for n_steps decisions, each lane's action is
  * MPCBitrateController.next_bitrate() (mpc.py:181-186) evaluated on the lane's OWN
  * environment state -- chunk_number = chunk_id, previous_bitrate = previous_bitrates[-1],
@@ -278,6 +317,16 @@ int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg, const double *br_t
 int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk, int32_t prev_bitrate,
                            double buffer_level, const double *pred_dev, const double *br_table_dev,
                            const double *sz_table_dev, double *J_out_dev, void *stream);
+
+/* Diagnostic: count independent chains "x <- fl(x + c), up to n times, stop right after the
+ * first result that is >= thr (stop_kind 0, c > 0), <= thr (1, c < 0) or < thr (2, c < 0)" --
+ * the float64 sequences of Simulator.py:160-163 and :184,:190-194 -- advanced by the kernels'
+ * exact closed form (csrc/abr_exact_jump.h) on the device.  estimate_bias 0 is the product
+ * path; +4 / -4 spoil the jump-length estimate so that the exact fallback search runs.
+ * Outputs per case: final x, additions performed, 1 if it stopped on the predicate. */
+int abr_debug_chain(int32_t stop_kind, int32_t estimate_bias, const double *x0_dev,
+                    const double *c_dev, const double *thr_dev, const int32_t *n_dev, int64_t count,
+                    double *x_out_dev, int32_t *a_out_dev, uint8_t *hit_out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,8 @@ int main(void) {
          offsetof(abr_env_config, interval));
   printf("%zu %zu %zu\n", sizeof(abr_mpc_config), offsetof(abr_mpc_config, chunk_length),
          offsetof(abr_mpc_config, startup_weight));
-  printf("%zu %zu\n", sizeof(abr_env_state_view), offsetof(abr_env_state_view, bw_hist));
+  printf("%zu %zu %zu %zu\n", sizeof(abr_env_state_view), offsetof(abr_env_state_view, bw_hist),
+         sizeof(abr_mpc_options), offsetof(abr_mpc_options, hist_len_dev));
   printf("%d %d %d %d\n", ABR_OBS_DIM, ABR_F64_DIM, ABR_MAX_RATES, ABR_MAX_HORIZON);
   return 0;
 }'''
@@ -68,7 +69,8 @@ int main(void) {
     M = L.MpcConfig
     assert b == [C.sizeof(M), M.chunk_length.offset, M.startup_weight.offset]
     c_ = list(map(int, out[2].split()))
-    assert c_ == [C.sizeof(L.StateView), L.StateView.bw_hist.offset]
+    assert c_ == [C.sizeof(L.StateView), L.StateView.bw_hist.offset, C.sizeof(L.MpcOptions),
+                  L.MpcOptions.hist_len_dev.offset]
     assert list(map(int, out[3].split())) == [L.OBS_DIM, L.F64_DIM, L.MAX_RATES, L.MAX_HORIZON]
     assert len(L.OBS_ROWS) == L.OBS_DIM and len(L.F64_ROWS) == L.F64_DIM
 

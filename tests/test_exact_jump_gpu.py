@@ -1,0 +1,104 @@
+"""The DEVICE build of the exact chain (csrc/abr_exact_jump.h: v_rcp_f64 estimate, saturating
+convert, out-of-line exact search) against the naive one-addition-per-tick loop run on the host,
+through the diagnostic entry point abr_debug_chain.  estimate_bias = +4 / -4 spoils the
+jump-length estimate on purpose so that the fallback search (jump_fix) -- never reached by
+real inputs, whose estimates are within one of the answer -- runs on the device too."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_exact_jump import H, _run  # noqa: F401  (host harness: jump chain == naive loop, asserted)
+
+pytestmark = pytest.mark.gpu
+
+GE, LE, LT = 0, 1, 2
+
+
+def _device(kind, bias, x0, c, thr, n):
+    from abrsimulator_amd import _lib
+    lib = _lib.lib()
+    t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, d)).cuda()
+    x0, c, thr, n = t(x0, np.float64), t(c, np.float64), t(thr, np.float64), t(n, np.int32)
+    N = x0.numel()
+    xo = torch.empty(N, dtype=torch.float64, device="cuda")
+    ao = torch.empty(N, dtype=torch.int32, device="cuda")
+    ho = torch.empty(N, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.abr_debug_chain(kind, bias, _lib.ptr(x0), _lib.ptr(c), _lib.ptr(thr), _lib.ptr(n), N,
+                                   _lib.ptr(xo), _lib.ptr(ao), _lib.ptr(ho), None))
+    torch.cuda.synchronize()
+    return xo.cpu().numpy(), ao.cpu().numpy(), ho.cpu().numpy()
+
+
+def _both(H, fn, kind, x0, c, thr, n, biases=(0, 4, -4)):
+    xh, ah, hh = _run(fn, x0, c, thr, n)              # host: chain == naive loop (asserted inside)
+    for b in biases:
+        xd, ad, hd = _device(kind, b, x0, c, thr, n)
+        bad = np.flatnonzero((xd.view(np.uint64) != xh.view(np.uint64)) | (ad != ah) | (hd != hh))
+        assert bad.size == 0, (kind, b, bad[:3], np.asarray(x0)[bad[:3]], np.asarray(c)[bad[:3]],
+                               xd[bad[:3]], xh[bad[:3]], ad[bad[:3]], ah[bad[:3]])
+
+
+def test_simulator_shapes_on_device(H):
+    rng = np.random.default_rng(11)
+    N = 200_000
+    c = rng.uniform(0.05, 12.0, N).astype(np.float32).astype(np.float64) * 0.01
+    x0 = np.where(rng.random(N) < 0.4, 0.0, rng.uniform(0, 20, N))
+    thr = rng.choice([0.3, 0.75, 1.2, 1.85, 2.85, 4.3], N) * rng.choice([1.0, 2.0, 4.0], N)
+    n = rng.integers(1, 3000, N)
+    _both(H, H.fuzz_ge, GE, x0, c, thr, n)
+    xb = np.where(rng.random(N) < 0.5, rng.integers(1, 7, N) * 4.0, rng.uniform(0.001, 30, N))
+    sd = rng.choice([0.01, 0.0125, 0.005, 0.02], N)
+    _both(H, H.fuzz_le, LE, xb, -sd, np.zeros(N), rng.integers(1, 4000, N))
+    t2 = rng.choice([20.0, 3.0, 5.0, 9.0], N)
+    _both(H, H.fuzz_lt, LT, t2 + rng.uniform(0, 5, N), -sd, t2, rng.integers(1, 4000, N))
+
+
+def test_ties_thresholds_and_wild_ranges_on_device(H):
+    rng = np.random.default_rng(12)
+    N = 100_000
+    e = rng.integers(-8, 6, N)
+    base = np.ldexp(1.0, e)
+    kmant = rng.integers(0, 1 << 20, N)
+    x0 = base * (1.0 + kmant * 2.0 ** -52)
+    u = base * 2.0 ** -52
+    c = rng.integers(1, 1 << 44, N).astype(np.float64) * u + u / 2       # ties in binade e
+    n = rng.integers(1, 500, N)
+    thr = x0 + c * rng.integers(1, 600, N)
+    for t in (thr, np.nextafter(thr, np.inf), np.nextafter(thr, -np.inf)):
+        _both(H, H.fuzz_ge, GE, x0, c, t, n)
+    x1 = base * (2.0 - kmant * 2.0 ** -52)
+    thr2 = np.maximum(x1 - c * rng.integers(1, 600, N), 0.0)
+    _both(H, H.fuzz_le, LE, x1, -c, thr2, n)
+    _both(H, H.fuzz_lt, LT, x1, -c, np.nextafter(thr2, np.inf), n)
+    xw = np.ldexp(rng.uniform(1, 2, N), rng.integers(-40, 40, N)) * (rng.random(N) > 0.1)
+    cw = np.ldexp(rng.uniform(1, 2, N), rng.integers(-45, 30, N))
+    nw = rng.integers(1, 2000, N)
+    _both(H, H.fuzz_ge, GE, xw, cw, xw + cw * rng.uniform(0, 3000, N), nw)
+    _both(H, H.fuzz_le, LE, xw, -cw, np.maximum(xw - cw * rng.uniform(0, 3000, N), -1.0), nw)
+
+
+def test_very_long_jumps_on_device(H):
+    """Jumps of up to 2^27 steps inside one binade: the regime in which a reciprocal estimate
+    could be off by more than one (it is not: v_rcp_f64 is good to an ulp or so; the biased
+    runs prove that the fallback would repair it if it were)."""
+    x0 = np.array([1.0, 1.0, 1.5, 1024.0, 1.0, 3.0])
+    c = np.array([2.0 ** -30, 2.0 ** -29 + 2.0 ** -52, 3 * 2.0 ** -31, 2.0 ** -17, 2.0 ** -28, 2.0 ** -27])
+    n = np.array([1 << 27, (1 << 27) + 12345, 1 << 26, 1 << 27, 99_999_999, 1 << 27], np.int32)
+    thr = np.array([10.0, 1.2, 1.9, 1e9, 1.3, 3.9])
+    _both(H, H.fuzz_ge, GE, x0, c, thr, n)
+    x1 = np.array([2.0 - 2.0 ** -52, 1.75, 2047.0, 3.999])
+    c1 = np.array([2.0 ** -30, 2.0 ** -29, 2.0 ** -18, 2.0 ** -27])
+    n1 = np.array([1 << 27, 1 << 26, 1 << 27, 1 << 27], np.int32)
+    _both(H, H.fuzz_le, LE, x1, -c1, np.array([0.0, 1.1, 1030.0, 2.5]), n1)
+    _both(H, H.fuzz_lt, LT, x1, -c1, np.array([1.5, 1.25, 1024.0, 2.0]), n1)
+
+
+def test_rejects_bad_arguments():
+    from abrsimulator_amd import _lib
+    lib = _lib.lib()
+    one = C.c_void_p(256)
+    assert lib.abr_debug_chain(3, 0, one, one, one, one, 4, one, one, one, None) == -1
+    assert lib.abr_debug_chain(0, 1, one, one, one, one, 4, one, one, one, None) == -1
+    assert lib.abr_debug_chain(0, 0, None, one, one, one, 4, one, one, one, None) == -1
