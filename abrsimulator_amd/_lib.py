@@ -72,6 +72,7 @@ SYMBOLS = [
     ("abr_env_set_lane_id_base", C.c_int, [_P, C.c_int64]),
     ("abr_env_set_impl", C.c_int, [_P, C.c_int32]),
     ("abr_env_set_lane_speeds", C.c_int, [_P, _P]),
+    ("abr_env_set_bitrate_table", C.c_int, [_P, _P]),
     ("abr_env_reset", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step_random", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),

@@ -119,6 +119,7 @@ struct EnvParams {
     double *buf, *last_bw, *hist_n, *hist_s;
     double *sd_lane, *pt_lane;     // per-lane speed*dt and play_time (only touched when lane_speeds != nullptr)
     const double *lane_speeds;     // caller-owned per-lane play speeds, or nullptr: one speed for all lanes
+    const double *br_table;        // caller-owned [video_length][n_rates] per-chunk ladders, or nullptr: `ladder`
     long long *sumk;               // sum of tick indices of playing ticks (latency integral)
     int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *j, *tpos, *trace_id, *offset0;
     int32_t *last_action, *n_su_obs, *n_rb_obs, *episode_no;
@@ -138,7 +139,15 @@ struct abr_env {
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds: latched into p.lane_speeds by the next full reset
     bool speeds_dirty;
+    const double *pending_br_table; // abr_env_set_bitrate_table: latched the same way
+    bool br_table_dirty;
 };
+
+// mpd.chunks[chunk].bitrates[rate]: the single ladder run() indexes (Simulator.py:82,156), or --
+// the evident intent of set_mpd's one-ladder-per-line file (Simulator.py:71-76) -- chunk's own
+__device__ inline double chunk_bitrate(const EnvParams &p, int32_t chunk, int32_t rate) {
+    return p.br_table ? p.br_table[(int64_t)chunk * p.n_rates + rate] : p.ladder[rate];
+}
 
 // ---------------------------------------------------------------------------
 // philox4x32-10 (Salmon et al. 2011) -- counter-based, so shards reproduce the
@@ -359,7 +368,9 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                     hist_s = hist_s + 1.0 / bw;        // sum(1/x), list order (mpc.py:86-88)
                     hist_n = hist_n + 1.0;
                     s.last_action = s.cur_action;
-                    if (prev_action >= 0) var = fabs(p.ladder[s.cur_action] - p.ladder[prev_action]);
+                    if (prev_action >= 0)
+                        var = fabs(chunk_bitrate(p, s.chunk_id - 1, s.cur_action) -
+                                   chunk_bitrate(p, s.chunk_id - 2, prev_action));
                 }
                 // per-step split of calculate_qoe (Simulator.py:83-85)
                 const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                 } else {
                     prev_action = s.last_action;
                     s.cur_action = a;
-                    s.target = p.ladder[a] * L;                      // :156
+                    s.target = chunk_bitrate(p, s.chunk_id, a) * L;   // :156
                     s.dl = 0.0; s.n_dl = 0; s.done_dl = false;
                     s.avail_next = p.avail_tick[s.chunk_id + 1];
                     s.running = true;          // T4 of this very tick comes next
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                     const int32_t prev_action = s.last_action;
                     const int32_t chunk = s.chunk_id;
                     const abrx::StepResult r = abrx::lanej_download_and_wait(
-                        s, tb, st, p.ladder[a] * p.chunk_length /* :156 */, a);
+                        s, tb, st, chunk_bitrate(p, chunk, a) * p.chunk_length /* :156 */, a);
                     double var = 0.0;
                     if (r.hit) {
                         const int64_t h = (int64_t)chunk * p.n_lanes + i;
@@ -638,7 +649,8 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                         last_bw = r.bw;
                         hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
                         hist_n = hist_n + 1.0;
-                        if (prev_action >= 0) var = fabs(p.ladder[a] - p.ladder[prev_action]);
+                        if (prev_action >= 0)
+                            var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
                     const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
@@ -793,7 +805,8 @@ __device__ __forceinline__ void split_role_download(
             abrx::Download d; d.dl = 0.0; d.n_dl = 0; d.hit = false;
             ABR_STAMP(2);
             if (a < 0 || a >= p.n_rates) flags |= kRecBadAct;
-            else d = abrx::lanej_download(cur, tb, st, d_k, p.ladder[a] * p.chunk_length /* :156 */);
+            else d = abrx::lanej_download(cur, tb, st, d_k,
+                                          chunk_bitrate(p, d_chunk, a) * p.chunk_length /* :156 */);
             ABR_STAMP(3);
             if (d.hit) flags |= kRecHit;
             m.dl[cb][l] = d.dl; m.n_dl[cb][l] = d.n_dl; m.k_start[cb][l] = d_k;
@@ -898,7 +911,8 @@ __device__ __forceinline__ void split_role_player(
                         last_bw = r.bw;
                         hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
                         hist_n = hist_n + 1.0;
-                        if (prev_action >= 0) var = fabs(p.ladder[a] - p.ladder[prev_action]);
+                        if (prev_action >= 0)
+                            var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
                     const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
@@ -993,7 +1007,7 @@ __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
     double variance = 0.0;
     for (int c = 0; c < p.video_length - 1; c++) {
         int a0 = acts[(int64_t)c * p.n_lanes + i], a1 = acts[(int64_t)(c + 1) * p.n_lanes + i];
-        variance += fabs(p.ladder[a0] - p.ladder[a1]);                   // :82
+        variance += fabs(chunk_bitrate(p, c, a0) - chunk_bitrate(p, c + 1, a1));   // :82
     }
     qoe_out[i] = p.wr * p.ep_qoe_terms[0 * p.n_lanes + i] + p.wv * variance +
                  p.ws * p.ep_qoe_terms[1 * p.n_lanes + i] +
@@ -1242,6 +1256,14 @@ extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
     return ABR_OK;
 }
 
+// per-chunk bitrate ladders [video_length][n_rates] (8f rank 2); nullptr restores the config ladder
+extern "C" int abr_env_set_bitrate_table(abr_env *env, const double *br_table_dev) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    env->pending_br_table = br_table_dev;
+    env->br_table_dirty = true;
+    return ABR_OK;
+}
+
 // lane id base for the counter-based policy when lanes are a shard of a bigger job
 extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
@@ -1256,6 +1278,13 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
                              float *obs_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!trace_id_dev) return fail(ABR_E_INVALID, "trace_id_dev is NULL");
+    if (env->br_table_dirty) {
+        if (lane_mask_dev)
+            return fail(ABR_E_INVALID, "abr_env_set_bitrate_table takes effect at a reset of ALL lanes "
+                        "(lane_mask_dev must be NULL for the first reset after it)");
+        env->p.br_table = env->pending_br_table;
+        env->br_table_dirty = false;
+    }
     if (env->speeds_dirty) {
         if (lane_mask_dev)
             return fail(ABR_E_INVALID, "abr_env_set_lane_speeds takes effect at a reset of ALL lanes "

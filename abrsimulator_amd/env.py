@@ -50,7 +50,19 @@ class BatchedABREnv:
             raise ValueError("BatchedABREnv runs on a ROCm device only (no CPU path exists)")
         self.n_lanes = int(n_lanes)
         self.mpd, self.qoe_metric, self.network_info = mpd, qoe_metric, network_info
-        ladder = mpd.ladder()
+        # one ladder for the whole video (what run() indexes, Simulator.py:82,156) or, for an MPD
+        # whose chunks differ (set_mpd's one-ladder-per-line file), a per-chunk table
+        self.br_table = None
+        if mpd.uniform():
+            ladder = mpd.ladder()
+        else:
+            table = mpd.bitrate_table()
+            if len(table) != int(mpd.video_length) or any(len(r) != len(table[0]) for r in table):
+                raise ValueError("a per-chunk MPD needs video_length ladders of equal length")
+            ladder = table[0]
+            self.br_table = torch.tensor(table, dtype=torch.float64, device=self.device).contiguous()
+            if not bool((self.br_table > 0).all()):
+                raise ValueError("bitrates must be > 0")
         cfg = _lib.EnvConfig()
         cfg.n_rates, cfg.video_length = len(ladder), int(mpd.video_length)
         cfg.chunk_length, cfg.max_buffer = float(mpd.chunk_length), float(mpd.max_buffer)
@@ -104,6 +116,8 @@ class BatchedABREnv:
         _lib.check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:
             _lib.check(self.lib.abr_env_set_lane_speeds(self._h, _lib.ptr(self.lane_speeds)))
+        if self.br_table is not None:
+            _lib.check(self.lib.abr_env_set_bitrate_table(self._h, _lib.ptr(self.br_table)))
         self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(self.n_lanes, dtype=torch.float32, device=self.device)
         self.done = torch.zeros(self.n_lanes, dtype=torch.uint8, device=self.device)

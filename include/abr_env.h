@@ -135,6 +135,16 @@ int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
  * Event-driven kernels only. */
 int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);   /* latched: see above */
 
+/* Per-chunk bitrate ladders: br_table_dev float64 [video_length][n_rates], caller-owned, valid
+ * from this call until the handle is destroyed or another call replaces it; NULL restores
+ * config.ladder.  This is the evident intent of set_mpd's one-ladder-per-line file
+ * (Simulator.py:71-76), which run() itself cannot consume (it indexes a single Chunk,
+ * Simulator.py:82,156, and raises AttributeError on the list) -- so it is BUILD-DEFINED:
+ * target_size = br[chunk_id][action] * chunk_length, and the variance term of calculate_qoe
+ * (and of the per-step reward) is |br[i][a_i] - br[i+1][a_(i+1)]|, each bitrate from its own
+ * chunk's ladder.  Latched like abr_env_set_lane_speeds: picked up by the next reset of ALL lanes. */
+int abr_env_set_bitrate_table(abr_env *env, const double *br_table_dev);
+
 /* Which kernels serve reset/step: 2 (default) = event-driven (exact closed-form stepping
  * of the float64 tick sequences) with each lane's download side and player side on two
  * waves of one workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per

@@ -34,7 +34,16 @@ typedef struct {
     double  latency_weight;
     double  speed;            /* constant returned by get_next_speed  Simulator.py:177   */
     double  ladder[16];       /* mpd.chunks.bitrates                                     */
+    /* Build-defined generalisation (the reference raises AttributeError when mpd.chunks is the
+     * list set_mpd builds, Simulator.py:71-76 vs :82,156): NULL, or [video_length][n_rates]
+     * per-chunk ladders -- target_size uses the downloading chunk's row, the variance term of
+     * calculate_qoe each chunk's own row.  Parity fixtures never set it. */
+    const double *br_table;
 } oracle_env_cfg;
+
+static inline double chunk_bitrate(const oracle_env_cfg *c, int chunk, int rate) {
+    return c->br_table ? c->br_table[(size_t)chunk * c->n_rates + rate] : c->ladder[rate];
+}
 
 /* what the ABR callback sees (Simulator.py:155) plus run()'s locals then */
 typedef struct {
@@ -124,7 +133,7 @@ int oracle_env_episode(const oracle_env_cfg *c, const double *trace, int32_t tra
                 current_bitrate = actions ? actions[chunk_id]
                                           : policy(ctx, &r, previous_bandwidths, chunk_id); /* :155 */
                 if (current_bitrate < 0 || current_bitrate >= c->n_rates) { rc = -3; break; }
-                target_size = c->ladder[current_bitrate] * c->chunk_length;               /* :156 */
+                target_size = chunk_bitrate(c, chunk_id, current_bitrate) * c->chunk_length; /* :156 */
             }
             int64_t bandwidth_idx = (int64_t)(global_time / c->interval);                 /* :158 */
             double bandwidth = trace[(offset + bandwidth_idx) % trace_len];                /* :159 */
@@ -167,7 +176,8 @@ int oracle_env_episode(const oracle_env_cfg *c, const double *trace, int32_t tra
         /* calculate_qoe, Simulator.py:79-86 */
         double variance = 0;
         for (int i = 0; i < V - 1; i++)
-            variance += fabs(c->ladder[previous_bitrates[i]] - c->ladder[previous_bitrates[i + 1]]);
+            variance += fabs(chunk_bitrate(c, i, previous_bitrates[i]) -
+                             chunk_bitrate(c, i + 1, previous_bitrates[i + 1]));
         fin->qoe = c->rebuffer_weight * rebuffer_time + c->variance_weight * variance
                  + c->startup_weight * start_up_time + c->latency_weight * average_latency;
         fin->rebuffer_time = rebuffer_time; fin->start_up_time = start_up_time;

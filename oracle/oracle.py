@@ -21,7 +21,7 @@ class EnvCfg(C.Structure):
                 ("start_up_length", C.c_double), ("interval", C.c_double),
                 ("rebuffer_weight", C.c_double), ("variance_weight", C.c_double),
                 ("startup_weight", C.c_double), ("latency_weight", C.c_double),
-                ("speed", C.c_double), ("ladder", C.c_double * 16)]
+                ("speed", C.c_double), ("ladder", C.c_double * 16), ("br_table", C.c_void_p)]
 
 
 class MpcCfg(C.Structure):
@@ -70,8 +70,14 @@ def _p(a, t):
 
 
 def env_cfg(ladder, chunk_length, video_length, max_buffer, start_up_length, interval,
-            weights, speed=1.0):
+            weights, speed=1.0, br_table=None):
+    """br_table: optional [video_length][n_rates] per-chunk ladders (build-defined VBR
+    generalisation; see abr_oracle.c).  The array is kept alive on the returned struct."""
     c = EnvCfg()
+    if br_table is not None:
+        c._br_keep = np.ascontiguousarray(br_table, np.float64)
+        assert c._br_keep.shape == (int(video_length), len(ladder))
+        c.br_table = c._br_keep.ctypes.data
     c.n_rates, c.video_length = len(ladder), int(video_length)
     c.chunk_length, c.max_buffer = float(chunk_length), float(max_buffer)
     c.start_up_length, c.interval = float(start_up_length), float(interval)

@@ -295,3 +295,67 @@ def test_mpc_previous_bitrate_outside_the_ladder_is_no_decision():
     assert (hn[[0, 5, 6]] == 4.0).all() and (hn[1:5] == 9.0).all()
     # Python's negative index: -6 is rate 0, -1 is rate 5
     assert float(ctl.last_J[1]) == float(ctl.last_J[3]) and float(ctl.last_J[2]) == float(ctl.last_J[4])
+
+
+# ---------------------------------------------------------------------------------------------
+# per-chunk ladders (8f rank 2, build-defined: the reference cannot run a list-MPD)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl", ["split", "jump", "tick"])
+def test_per_chunk_ladders_against_oracle(oracle, impl, tmp_path):
+    import abrsimulator_amd as A
+    rng = np.random.default_rng(66)
+    VV, N = 14, 384
+    br = np.array(LADDER)[None, :] * rng.uniform(0.7, 1.3, (VV, 6))
+    traces = _traces(8, seed=6)
+    # through the file format: one ladder per line (Simulator.py:71-76)
+    mpdfile = str(tmp_path / "vbr.mpd")
+    A.save_mpd_file(mpdfile, br)
+    mpd = A.load_mpd_file(L, MAX_BUFFER, START_UP, mpdfile)
+    assert not mpd.uniform() and np.array_equal(np.array(mpd.bitrate_table()), br)
+    tid = rng.integers(0, 8, N).astype(np.int32); off = rng.integers(0, 1000, N).astype(np.int32)
+    actions = rng.integers(0, 6, (N, VV)).astype(np.int32)
+    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(1.0, traces), N, impl=impl)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    cfg = oracle.env_cfg(LADDER, L, VV, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0, br_table=br)
+    steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, actions)
+    acts = torch.from_numpy(actions).cuda()
+    rew = np.zeros(N)
+    for s in range(VV):
+        f = env.observe_f64()
+        for k in ("global_time", "buffer_level", "rebuffer_time", "start_up_time", "play_time"):
+            assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (s, k)
+        _, r, _ = env.step(acts[:, s].contiguous())
+        rew += r.double().cpu().numpy()
+    assert np.array_equal(env.history()[1].cpu().numpy().T, bw)
+    q = env.episode_qoe().cpu().numpy()
+    assert np.allclose(q, fin["qoe"], rtol=1e-10)
+    # the per-step rewards still add up to calculate_qoe
+    assert np.allclose(rew + 0.1 * fin["average_latency"], fin["qoe"], rtol=2e-5, atol=1e-3)
+    # and it is not the single-ladder answer
+    cfg1 = oracle.env_cfg(list(br[0]), L, VV, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
+    _, bw1, _, _ = oracle.env_batch(cfg1, traces, tid, off, actions)
+    assert not np.array_equal(bw1, bw)
+
+
+def test_fused_random_rollout_with_per_chunk_ladders(oracle):
+    import abrsimulator_amd as A
+    rng = np.random.default_rng(67)
+    VV, N, SEED = 10, 512, 5
+    br = np.array(LADDER)[None, :] * rng.uniform(0.7, 1.3, (VV, 6))
+    traces = _traces(8, seed=7)
+    mpd = A.MPD(VV, L, MAX_BUFFER, START_UP, [A.Chunk(list(r)) for r in br])
+    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(1.0, traces), N, auto_reset=True)
+    tid = (np.arange(N) % 8).astype(np.int32); off = rng.integers(0, 1000, N).astype(np.int32)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    out = env.step_random(2 * VV, SEED)
+    acts = out["actions"].cpu().numpy()
+    cfg = oracle.env_cfg(LADDER, L, VV, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0, br_table=br)
+    for ep in range(2):
+        a = acts[ep * VV:(ep + 1) * VV].T.copy()
+        assert np.array_equal(a, np.stack([philox_action(SEED, np.arange(N), s, ep, 6) for s in range(VV)], 1))
+        steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, a)
+        o = out["obs"].cpu().numpy()[ep * VV:(ep + 1) * VV]
+        for s in range(VV - 1):
+            assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), (ep, s)
+            assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32)), (ep, s)
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
