@@ -73,6 +73,7 @@ SYMBOLS = [
     ("abr_env_set_impl", C.c_int, [_P, C.c_int32]),
     ("abr_env_set_lane_speeds", C.c_int, [_P, _P]),
     ("abr_env_set_bitrate_table", C.c_int, [_P, _P]),
+    ("abr_env_set_speed_schedule", C.c_int, [_P, _P, C.c_int32]),
     ("abr_env_reset", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step_random", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),

@@ -118,7 +118,10 @@ struct EnvParams {
     // per-lane state, SoA (device, in the workspace)
     double *buf, *last_bw, *hist_n, *hist_s;
     double *sd_lane, *pt_lane;     // per-lane speed*dt and play_time (only touched when lane_speeds != nullptr)
-    const double *lane_speeds;     // caller-owned per-lane play speeds, or nullptr: one speed for all lanes
+    const double *lane_speeds;     // caller-owned per-lane play speeds [speed_rows][n_lanes], or nullptr: one speed for all lanes
+    int32_t speed_rows;            // 1: one constant speed per lane; >= 2: a schedule, one row per played chunk
+    int32_t *pl_left, *play_id;    // speed schedule only: playing ticks left in the played chunk, chunks played
+    double *pt_sum;                // speed schedule only: sum of play_time over the playing ticks
     const double *br_table;        // caller-owned [video_length][n_rates] per-chunk ladders, or nullptr: `ladder`
     long long *sumk;               // sum of tick indices of playing ticks (latency integral)
     int32_t *k, *chunk_id, *n_su, *n_rb, *n_play, *j, *tpos, *trace_id, *offset0;
@@ -137,7 +140,8 @@ struct abr_env {
     int impl;   // 2 = role-split event-driven kernels (default), 0 = one thread per lane,
                 // 1 = tick-by-tick kernels (cross-check)
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
-    const double *pending_speeds;   // abr_env_set_lane_speeds: latched into p.lane_speeds by the next full reset
+    const double *pending_speeds;   // abr_env_set_lane_speeds / _speed_schedule: latched by the next full reset
+    int32_t pending_speed_rows;
     bool speeds_dirty;
     const double *pending_br_table; // abr_env_set_bitrate_table: latched the same way
     bool br_table_dirty;
@@ -257,6 +261,12 @@ __device__ inline double avg_latency_from(double sd, double play_time, long long
 }
 __device__ inline double lane_avg_latency(const EnvParams &p, long long sumk, int32_t n_play) {
     return avg_latency_from(p.sd, p.GP[n_play], sumk, n_play);
+}
+// with a speed schedule play_time is not n_play equal steps: the sum of play_time over the playing
+// ticks is carried instead of the closed form sd * n(n-1)/2
+__device__ inline double avg_latency_sched(double play_time, long long sumk, double pt_sum, int32_t n_play) {
+    if (n_play == 0) return 0.0;
+    return (kDt * (double)sumk - pt_sum) / play_time;
 }
 
 __device__ inline void lane_load(Lane &s, const EnvParams &p, int64_t i) {
@@ -527,6 +537,8 @@ __device__ inline abrx::Tables make_tables(const EnvParams &p) {
     t.L = p.chunk_length; t.sd = p.sd; t.max_buffer = p.max_buffer;
     t.start_up_length = p.start_up_length; t.V = p.video_length; t.max_ticks = p.max_ticks;
     t.per_lane_speed = p.lane_speeds != nullptr;
+    t.speed_rows = p.lane_speeds ? p.speed_rows : 0;
+    t.speed_stride = p.n_lanes; t.speeds = p.lane_speeds;
     return t;
 }
 
@@ -540,6 +552,8 @@ __device__ inline void lanej_load(LaneJ &s, const EnvParams &p, int64_t i) {
     const int32_t c = s.chunk_id < p.video_length ? s.chunk_id : p.video_length;
     s.avail_k = p.avail_tick[c];
     if (p.lane_speeds) { s.sd = p.sd_lane[i]; s.pt = p.pt_lane[i]; } else { s.sd = p.sd; s.pt = 0.0; }
+    s.lane = i; s.pl_left = 0; s.play_id = 0; s.pt_sum = 0.0;
+    if (p.lane_speeds && p.speed_rows >= 2) { s.pl_left = p.pl_left[i]; s.play_id = p.play_id[i]; s.pt_sum = p.pt_sum[i]; }
 }
 
 __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i) {
@@ -549,6 +563,7 @@ __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
                            (s.bf ? kFlagBufFull : 0) | kFlagArmed);
     if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
+    if (p.lane_speeds && p.speed_rows >= 2) { p.pl_left[i] = s.pl_left; p.play_id[i] = s.play_id; p.pt_sum[i] = s.pt_sum; }
 }
 
 __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i, float *obs,
@@ -598,6 +613,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.cur.tlen = p.trace_len[t]; s.cur.trace = p.traces + p.trace_off[t];
                 s.sd = p.lane_speeds ? p.lane_speeds[i] * kDt : p.sd;     // play_speed * dt (:182)
+                s.lane = i;
                 abrx::lanej_init(s, tb, offset0);
                 if (!bad && !abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                 write_obs_j(s, p, i, obs_out, 0.0);
@@ -665,8 +681,9 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
                         p.ep_qoe_terms[2 * p.n_lanes + i] =
-                            p.lane_speeds ? avg_latency_from(s.sd, s.pt, s.sumk, s.n_play)
-                                          : lane_avg_latency(p, s.sumk, s.n_play);
+                            !p.lane_speeds ? lane_avg_latency(p, s.sumk, s.n_play)
+                            : (p.speed_rows >= 2 ? avg_latency_sched(s.pt, s.sumk, s.pt_sum, s.n_play)
+                                                 : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
                             for (int c = 0; c < V; c++)
@@ -740,6 +757,7 @@ __device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, in
     p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
                            (s.bf ? kFlagBufFull : 0) | kFlagArmed);
     if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
+    if (p.lane_speeds && p.speed_rows >= 2) { p.pl_left[i] = s.pl_left; p.play_id[i] = s.play_id; p.pt_sum[i] = s.pt_sum; }
 }
 
 #ifdef ABR_SPLIT_STAMPS
@@ -928,8 +946,9 @@ __device__ __forceinline__ void split_role_player(
                         p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                         p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
                         p.ep_qoe_terms[2 * p.n_lanes + i] =
-                            p.lane_speeds ? avg_latency_from(s.sd, s.pt, s.sumk, s.n_play)
-                                          : lane_avg_latency(p, s.sumk, s.n_play);
+                            !p.lane_speeds ? lane_avg_latency(p, s.sumk, s.n_play)
+                            : (p.speed_rows >= 2 ? avg_latency_sched(s.pt, s.sumk, s.pt_sum, s.n_play)
+                                                 : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
                             for (int c = 0; c < V; c++)
@@ -1022,20 +1041,29 @@ __global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
     out[ABR_F64_REBUFFER_TIME * n + i] = p.G[p.n_rb[i]];
     out[ABR_F64_STARTUP_TIME * n + i] = p.G[p.n_su[i]];
     int32_t P = p.play_ticks_per_chunk;
+    const bool sched = p.lane_speeds && p.speed_rows >= 2;
     if (p.lane_speeds) {
         // per-lane speed: ticks per played chunk = additions of speed*dt from 0 until >= L (:185)
         double x = 0.0; int32_t a = 0;
         abrx::chain<abrx::STOP_GE>(x, p.sd_lane[i], p.chunk_length, p.max_ticks + 1, a);
         P = a > 0 ? a : 1;
         out[ABR_F64_PLAY_TIME * n + i] = p.pt_lane[i];
-        out[ABR_F64_AVERAGE_LATENCY * n + i] = avg_latency_from(p.sd_lane[i], p.pt_lane[i], p.sumk[i], p.n_play[i]);
+        out[ABR_F64_AVERAGE_LATENCY * n + i] =
+            sched ? avg_latency_sched(p.pt_lane[i], p.sumk[i], p.pt_sum[i], p.n_play[i])
+                  : avg_latency_from(p.sd_lane[i], p.pt_lane[i], p.sumk[i], p.n_play[i]);
     } else {
         out[ABR_F64_PLAY_TIME * n + i] = p.GP[p.n_play[i]];
         out[ABR_F64_AVERAGE_LATENCY * n + i] = lane_avg_latency(p, p.sumk[i], p.n_play[i]);
     }
     out[ABR_F64_BUFFER_LEVEL * n + i] = p.buf[i];
     // play_length restarts from 0 every P playing ticks (:185-187); play_id counts the restarts
-    if (p.lane_speeds) {
+    if (sched) {
+        // ticks already played of the current played chunk at its speed (0 between chunks)
+        const int32_t pl = p.pl_left[i];
+        double x = 0.0; int32_t a = 0;
+        abrx::chain<abrx::STOP_GE>(x, p.sd_lane[i], 1.0e300, pl > 0 ? P - pl : 0, a);
+        out[ABR_F64_PLAY_LENGTH * n + i] = x;
+    } else if (p.lane_speeds) {
         double x = 0.0; int32_t a = 0;
         abrx::chain<abrx::STOP_GE>(x, p.sd_lane[i], 1.0e300, p.n_play[i] % P, a);
         out[ABR_F64_PLAY_LENGTH * n + i] = x;
@@ -1044,7 +1072,7 @@ __global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
     }
     out[ABR_F64_LAST_BANDWIDTH * n + i] = p.last_bw[i];
     out[ABR_F64_CHUNK_ID * n + i] = (double)p.chunk_id[i];
-    out[ABR_F64_PLAY_ID * n + i] = (double)(p.n_play[i] / P);
+    out[ABR_F64_PLAY_ID * n + i] = sched ? (double)p.play_id[i] : (double)(p.n_play[i] / P);
     out[ABR_F64_LAST_BITRATE * n + i] = (double)p.last_action[i];
     out[ABR_F64_FLAGS * n + i] = (double)p.flags[i];
     out[ABR_F64_HIST_N * n + i] = p.hist_n[i];
@@ -1122,9 +1150,9 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->GP = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
     L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 8), A);
     L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
-    L->f64_state = o; o = align_up(o + sizeof(double) * 6 * N, A);
+    L->f64_state = o; o = align_up(o + sizeof(double) * 7 * N, A);
     L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);
-    L->i32_state = o; o = align_up(o + sizeof(int32_t) * 13 * N, A);
+    L->i32_state = o; o = align_up(o + sizeof(int32_t) * 15 * N, A);
     L->u8_state = o; o = align_up(o + 2 * N, A);
     L->action_hist = o; o = align_up(o + V * N, A);
     L->bw_hist = o; o = align_up(o + sizeof(double) * V * N, A);
@@ -1197,13 +1225,14 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     const size_t N = (size_t)n_lanes;
     double *f = (double *)(w + L.f64_state);
     p.buf = f; p.last_bw = f + N; p.hist_n = f + 2 * N; p.hist_s = f + 3 * N;
-    p.sd_lane = f + 4 * N; p.pt_lane = f + 5 * N; p.lane_speeds = nullptr;
+    p.sd_lane = f + 4 * N; p.pt_lane = f + 5 * N; p.pt_sum = f + 6 * N; p.lane_speeds = nullptr;
+    p.speed_rows = 1;
     p.sumk = (long long *)(w + L.i64_state);
     int32_t *q = (int32_t *)(w + L.i32_state);
     p.k = q; p.chunk_id = q + N; p.n_su = q + 2 * N; p.n_rb = q + 3 * N; p.n_play = q + 4 * N;
     p.j = q + 5 * N; p.tpos = q + 6 * N; p.trace_id = q + 7 * N; p.offset0 = q + 8 * N;
     p.last_action = q + 9 * N; p.n_su_obs = q + 10 * N; p.n_rb_obs = q + 11 * N;
-    p.episode_no = q + 12 * N;
+    p.episode_no = q + 12 * N; p.pl_left = q + 13 * N; p.play_id = q + 14 * N;
     uint8_t *u = (uint8_t *)(w + L.u8_state);
     p.flags = u; p.done = u + N;
     p.action_hist = (uint8_t *)(w + L.action_hist);
@@ -1252,6 +1281,19 @@ extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
     // latched by the next FULL abr_env_reset: until then the running episodes keep the
     // speeds (and the carried play_time) they were started with
     env->pending_speeds = speeds_dev;
+    env->pending_speed_rows = 1;
+    env->speeds_dirty = true;
+    return ABR_OK;
+}
+
+// a speed controller's answers, one row per played chunk (8f rank 3): speeds_dev [n_rows][n_lanes]
+extern "C" int abr_env_set_speed_schedule(abr_env *env, const double *speeds_dev, int32_t n_rows) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (speeds_dev && env->impl == 1)
+        return fail(ABR_E_UNSUPPORTED, "speed schedules need the event-driven kernels (impl 0 or 2)");
+    if (speeds_dev && n_rows < 1) return fail(ABR_E_INVALID, "n_rows must be >= 1");
+    env->pending_speeds = speeds_dev;
+    env->pending_speed_rows = speeds_dev ? n_rows : 1;
     env->speeds_dirty = true;
     return ABR_OK;
 }
@@ -1290,6 +1332,7 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
             return fail(ABR_E_INVALID, "abr_env_set_lane_speeds takes effect at a reset of ALL lanes "
                         "(lane_mask_dev must be NULL for the first reset after it)");
         env->p.lane_speeds = env->pending_speeds;
+        env->p.speed_rows = env->pending_speed_rows;
         env->speeds_dirty = false;
     }
     hipLaunchKernelGGL(env->impl == 1 ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,

@@ -46,6 +46,12 @@ struct Tables {
     double L, sd, max_buffer, start_up_length;
     int32_t V, max_ticks;
     bool per_lane_speed;           // each lane carries its own speed*dt and play_time (8f rank 3)
+    // speed schedule (8f rank 3, second half): speed_rows >= 2 means the lane's play speed is
+    // re-read at the first playing tick of every played chunk (play_length == 0, :176-177):
+    // played chunk p of lane i plays at speeds[min(p, speed_rows - 1) * speed_stride + i]
+    int32_t speed_rows;
+    int64_t speed_stride;
+    const double *speeds;
 };
 
 // Where a lane is in its bandwidth trace.  Only the download side (phase A) reads it.
@@ -64,6 +70,12 @@ struct LaneJ {
     int32_t k, chunk_id, n_su, n_rb, n_play, avail_k, last_action;
     bool su, be, bf;               // start_up, buffer_empty, buffer_full
     Cursor cur;
+    // speed schedule only: playing ticks left in the current played chunk (0: the next playing
+    // tick starts one and asks for its speed), chunks played so far (play_id), the sum of
+    // play_time over the playing ticks (latency integral), and the lane's column in `speeds`
+    int32_t pl_left, play_id;
+    double pt_sum;
+    int64_t lane;
 };
 
 ABR_HD void cursor_init(Cursor &c, int32_t offset0) {
@@ -79,6 +91,7 @@ ABR_HD void lanej_init_player(LaneJ &s, const Tables &t) {
     s.su = true; s.be = true; s.bf = false;
     s.avail_k = t.avail_tick[0];
     s.pt = 0.0;                    // play_time = 0 (:115); s.sd is set by the caller
+    s.pl_left = 0; s.play_id = 0; s.pt_sum = 0.0;      // play_length = 0, play_id = 0 (:113-114)
 }
 
 ABR_HD void lanej_init(LaneJ &s, const Tables &t, int32_t offset0) {
@@ -120,6 +133,51 @@ ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     return a > 0 && b <= 0.0;
 }
 
+// ---- speed schedule: the play speed changes at played-chunk boundaries ----
+// The first playing tick of a played chunk (play_length == 0) takes the chunk's speed
+// (:176-177); the chunk then lasts until play_length, `speed*dt` added per tick from 0, is
+// >= chunk_length (:183,:185-187): that many ticks, by the same exact chain.
+ABR_HD void sched_begin_chunk(LaneJ &s, const Tables &t) {
+    const int32_t row = s.play_id < t.speed_rows ? s.play_id : t.speed_rows - 1;
+    s.sd = t.speeds[(int64_t)row * t.speed_stride + s.lane] * kTickDt;     // play_speed * dt (:182)
+    double x = 0.0;
+    int32_t a = 0;
+    chain<STOP_GE>(x, s.sd, t.L, t.max_ticks + 1, a);
+    s.pl_left = a > 0 ? a : 1;
+}
+
+// bookkeeping of `a` playing ticks inside one played chunk: play_time (exact chain), the sum of
+// play_time over those ticks (real arithmetic: it only feeds average_latency), chunk boundary
+ABR_HD void sched_played(LaneJ &s, const Tables &t, int32_t a) {
+    if (a <= 0) return;
+    s.pt_sum += (double)a * s.pt + s.sd * (double)(((long long)a * (a - 1)) / 2);
+    int32_t done = 0;
+    double x = s.pt;
+    chain<STOP_GE>(x, s.sd, 1.0e300, a, done);
+    s.pt = x;
+    s.pl_left -= a;
+    if (s.pl_left == 0) s.play_id++;                                       // :185-187
+}
+
+// buffer_level -= speed*dt for up to m playing ticks, stopping right after the first result that
+// is <= 0 (STOP_LE, :194) or < thr (STOP_LT, :190), one played chunk at a time
+template <int STOP>
+ABR_HD bool sched_drain(LaneJ &s, const Tables &t, double &b, double thr, int32_t m, int32_t &a_out) {
+    int32_t a_tot = 0;
+    bool hit = false;
+    while (a_tot < m && !hit) {
+        if (s.pl_left == 0) sched_begin_chunk(s, t);
+        const int32_t run = (m - a_tot < s.pl_left) ? m - a_tot : s.pl_left;
+        int32_t a = 0;
+        if (STOP == STOP_LE) hit = drain_to_zero(b, s.sd, run, a);
+        else hit = chain<STOP_LT>(b, -s.sd, thr, run, a);
+        sched_played(s, t, a);
+        a_tot += a;
+    }
+    a_out = a_tot;
+    return hit;
+}
+
 // m full iterations: T4-T9 of a tick in which no chunk completes, then T1-T3 of the next
 ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     if (m <= 0) return;
@@ -134,8 +192,9 @@ ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     } else {
         int32_t a = 0;
         double b = s.buf;
-        const bool zero = drain_to_zero(b, s.sd, m, a);                        // :184,:194
-        lanej_play(s, t, a);
+        bool zero;
+        if (t.speed_rows >= 2) zero = sched_drain<STOP_LE>(s, t, b, 0.0, m, a);
+        else { zero = drain_to_zero(b, s.sd, m, a); lanej_play(s, t, a); }     // :184,:194
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
         if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
@@ -165,8 +224,9 @@ ABR_HD bool lanej_wait_call(LaneJ &s, const Tables &t) {
         }
         int32_t a = 0;
         double b = s.buf;
-        const bool cleared = chain<STOP_LT>(b, -s.sd, t.max_buffer, mt - s.k, a);
-        lanej_play(s, t, a);
+        bool cleared;
+        if (t.speed_rows >= 2) cleared = sched_drain<STOP_LT>(s, t, b, t.max_buffer, mt - s.k, a);
+        else { cleared = chain<STOP_LT>(b, -s.sd, t.max_buffer, mt - s.k, a); lanej_play(s, t, a); }
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
         s.k += a;
@@ -336,7 +396,14 @@ ABR_HD StepResult lanej_after_download(LaneJ &s, const Tables &t, const Download
     // ---- the completing tick (:163-170, then :174-202) ----
     const bool playing = !(s.be || s.su);
     double b = s.buf + t.L;                                                  // :170
-    if (playing) { s.sumk += s.k; s.n_play++; b = b - s.sd; lanej_play(s, t, 1); }   // :182-184
+    if (playing) {                                                            // :176-184
+        s.sumk += s.k; s.n_play++;
+        if (t.speed_rows >= 2) {
+            if (s.pl_left == 0) sched_begin_chunk(s, t);
+            b = b - s.sd;
+            sched_played(s, t, 1);
+        } else { b = b - s.sd; lanej_play(s, t, 1); }
+    }
     s.bf = b >= t.max_buffer;                                                // :190
     s.be = b <= 0.0;                                                         // :194
     if (s.be) b = 0.0;

@@ -73,10 +73,15 @@ class BatchedABREnv:
         cfg.latency_weight = float(getattr(qoe_metric, "latency_weight", 0.0))
         self.lane_speeds = None
         if torch.is_tensor(speed) or hasattr(speed, "__len__"):
-            # one constant play speed per lane
-            ls = torch.as_tensor(speed, dtype=torch.float64).reshape(-1)
-            if ls.numel() != self.n_lanes or not bool((ls > 0).all()) or not bool(torch.isfinite(ls).all()):
-                raise ValueError("per-lane speeds must be n_lanes finite values > 0")
+            # per-lane play speeds: [N] = one constant speed per lane;
+            # [rows, N] = a speed controller's answers, one row per played chunk
+            # (Simulator.py:176-177; the last row repeats)
+            ls = torch.as_tensor(speed, dtype=torch.float64)
+            if ls.dim() == 1:
+                ls = ls.reshape(1, -1)
+            if (ls.dim() != 2 or ls.shape[1] != self.n_lanes or ls.shape[0] < 1
+                    or not bool((ls > 0).all()) or not bool(torch.isfinite(ls).all())):
+                raise ValueError("per-lane speeds must be [n_lanes] or [rows, n_lanes] finite values > 0")
             self.lane_speeds = ls.to(self.device).contiguous()
             speed = 1.0
         cfg.speed = float(speed)
@@ -115,7 +120,8 @@ class BatchedABREnv:
         self.impl = impl
         _lib.check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:
-            _lib.check(self.lib.abr_env_set_lane_speeds(self._h, _lib.ptr(self.lane_speeds)))
+            _lib.check(self.lib.abr_env_set_speed_schedule(self._h, _lib.ptr(self.lane_speeds),
+                                                           int(self.lane_speeds.shape[0])))
         if self.br_table is not None:
             _lib.check(self.lib.abr_env_set_bitrate_table(self._h, _lib.ptr(self.br_table)))
         self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)

@@ -11,8 +11,9 @@ GPU environment, so a script written against the reference keeps its calls:
 buffer_level)` keeps the reference's signature (Simulator.py:155) with tensors over
 lanes: chunk_id int32[N]; previous_bitrates uint8[V, N] and previous_bandwidths
 float64[V, N] (rows < chunk_id are the lists' contents); buffer_level float64[N].
-It returns int32[N] bitrate indices.  `speed_controller.get_next_speed()` is asked
-once: the build takes a constant playback speed (D8: no speed controller ships).
+It returns int32[N] bitrate indices.  `speed_controller.get_next_speed()` keeps the
+reference's meaning -- the speed of the next played chunk (Simulator.py:176-177) -- and is asked
+video_length times before the run (see Simulator._speeds).
 """
 import torch
 
@@ -71,10 +72,22 @@ class Simulator(object):
         """calculate_qoe (Simulator.py:79-86) of the finished episodes."""
         return self.env.episode_qoe()
 
+    def _speeds(self):
+        """The reference asks speed_controller.get_next_speed() at the first playing tick of
+        every played chunk (Simulator.py:176-177); a video has at most video_length of them,
+        so the controller is asked that many times up front and its answers -- floats, or
+        tensors over lanes -- become the device-side schedule (one row per played chunk).
+        A controller that always answers the same float runs on the cheaper constant path."""
+        answers = [self.speed_controller.get_next_speed() for _ in range(int(self.mpd.video_length))]
+        if all(not torch.is_tensor(a) and not hasattr(a, "__len__") for a in answers):
+            if all(float(a) == float(answers[0]) for a in answers):
+                return float(answers[0])
+        rows = [torch.as_tensor(a, dtype=torch.float64).reshape(-1).expand(self.n_lanes) for a in answers]
+        return torch.stack(rows)
+
     def run(self):
-        speed = float(self.speed_controller.get_next_speed())
         self.env = BatchedABREnv(self.mpd, self.qoe_metric, self.network_info, self.n_lanes,
-                                 device=self.device, speed=speed)
+                                 device=self.device, speed=self._speeds())
         env = self.env
         env.reset(self.trace_id, self.start_offset)
         chunk_id, _, buffer_level, _, _, done = env.mpc_inputs()

@@ -135,6 +135,13 @@ int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
  * Event-driven kernels only. */
 int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);   /* latched: see above */
 
+/* What a speed controller answers, call by call (Simulator.py:176-177: get_next_speed() is
+ * asked at the first playing tick of every played chunk, i.e. whenever play_length == 0).
+ * speeds_dev: float64 [n_rows][n_lanes]; the p-th played chunk of lane i plays at
+ * speeds_dev[min(p, n_rows - 1) * n_lanes + i] (the last row repeats).  n_rows == 1 is
+ * abr_env_set_lane_speeds.  Same lifetime and latching rules.  Event-driven kernels only. */
+int abr_env_set_speed_schedule(abr_env *env, const double *speeds_dev, int32_t n_rows);
+
 /* Per-chunk bitrate ladders: br_table_dev float64 [video_length][n_rates], caller-owned, valid
  * from this call until the handle is destroyed or another call replaces it; NULL restores
  * config.ladder.  This is the evident intent of set_mpd's one-ladder-per-line file

@@ -39,6 +39,12 @@ typedef struct {
      * per-chunk ladders -- target_size uses the downloading chunk's row, the variance term of
      * calculate_qoe each chunk's own row.  Parity fixtures never set it. */
     const double *br_table;
+    /* speed controller (Simulator.py:176-177): NULL = the constant `speed`; else the answer to
+     * the p-th get_next_speed() call -- one call per played chunk, at its first playing tick --
+     * is speed_sched[min(p, speed_rows - 1) * speed_stride] */
+    const double *speed_sched;
+    int32_t speed_rows;
+    int64_t speed_stride;
 } oracle_env_cfg;
 
 static inline double chunk_bitrate(const oracle_env_cfg *c, int chunk, int rate) {
@@ -104,6 +110,7 @@ int oracle_env_episode(const oracle_env_cfg *c, const double *trace, int32_t tra
     const double dt = 0.01;                                   /* :133 */
     int64_t ticks = 0;
     int rc = 0;
+    int speed_calls = 0;                                       /* get_next_speed() calls so far */
 
     while (!simulation_end) {                                  /* :135 */
         if (ticks >= max_ticks) { rc = -2; break; }
@@ -150,7 +157,13 @@ int oracle_env_episode(const oracle_env_cfg *c, const double *trace, int32_t tra
         }
         /* :174-187 */
         if (!play_pause) {
-            if (play_length == 0) play_speed = c->speed;                                   /* :176-177 */
+            if (play_length == 0) {                                                        /* :176-177 */
+                if (c->speed_sched) {
+                    int row = speed_calls < c->speed_rows ? speed_calls : c->speed_rows - 1;
+                    play_speed = c->speed_sched[(size_t)row * c->speed_stride];
+                    speed_calls++;
+                } else play_speed = c->speed;
+            }
             instant_latency = global_time - play_time;                                     /* :179 */
             average_latency = (average_latency * play_time + instant_latency)
                               / (play_time + play_speed * dt);                             /* :180 */
@@ -233,6 +246,33 @@ int64_t oracle_env_batch_speeds(const oracle_env_cfg *c, const double *traces,
     for (int32_t i = 0; i < n_lanes; i++) {
         oracle_env_cfg ci = *c;
         ci.speed = speeds[i];
+        oracle_final_rec f;
+        int t = trace_id[i];
+        int rc = oracle_env_episode(&ci, traces + trace_off[t], trace_len[t], offset[i],
+                                    actions + (size_t)i * V, NULL, NULL,
+                                    steps ? steps + (size_t)i * V : NULL,
+                                    bw_out ? bw_out + (size_t)i * V : NULL, NULL, &f, max_ticks);
+        if (rc) return rc;
+        if (fin) fin[i] = f;
+        total += f.ticks;
+    }
+    return total;
+}
+
+/* Same, with a per-lane speed schedule: speeds[n_lanes][rows], the answers of lane i's speed
+ * controller to its successive get_next_speed() calls (the last one repeats). */
+int64_t oracle_env_batch_sched(const oracle_env_cfg *c, const double *traces,
+                               const int64_t *trace_off, const int32_t *trace_len,
+                               const int32_t *trace_id, const int32_t *offset,
+                               const int32_t *actions, const double *speeds, int32_t rows,
+                               int32_t n_lanes, oracle_step_rec *steps, double *bw_out,
+                               oracle_final_rec *fin, int64_t max_ticks)
+{
+    const int V = c->video_length;
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_lanes; i++) {
+        oracle_env_cfg ci = *c;
+        ci.speed_sched = speeds + (size_t)i * rows; ci.speed_rows = rows; ci.speed_stride = 1;
         oracle_final_rec f;
         int t = trace_id[i];
         int rc = oracle_env_episode(&ci, traces + trace_off[t], trace_len[t], offset[i],

@@ -21,7 +21,8 @@ class EnvCfg(C.Structure):
                 ("start_up_length", C.c_double), ("interval", C.c_double),
                 ("rebuffer_weight", C.c_double), ("variance_weight", C.c_double),
                 ("startup_weight", C.c_double), ("latency_weight", C.c_double),
-                ("speed", C.c_double), ("ladder", C.c_double * 16), ("br_table", C.c_void_p)]
+                ("speed", C.c_double), ("ladder", C.c_double * 16), ("br_table", C.c_void_p),
+                ("speed_sched", C.c_void_p), ("speed_rows", C.c_int32), ("speed_stride", C.c_int64)]
 
 
 class MpcCfg(C.Structure):
@@ -59,6 +60,7 @@ def lib():
         _LIB.oracle_env_batch.restype = C.c_int64
         _LIB.oracle_env_batch_speeds.restype = C.c_int64
         _LIB.oracle_env_batch_mpc.restype = C.c_int64
+        _LIB.oracle_env_batch_sched.restype = C.c_int64
         _LIB.oracle_mpc_brute.restype = C.c_int64
         _LIB.oracle_mpc_objective.restype = C.c_double
         assert STEP_DTYPE.itemsize == 96 and FINAL_DTYPE.itemsize == 72
@@ -100,7 +102,8 @@ def pack_traces(traces):
 def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=None,
               want_steps=True):
     """Replay episodes. traces: list of arrays. actions: [N, V] int32.  speeds: optional
-    per-lane constant play speeds [N] (default: cfg.speed for every lane).
+    per-lane constant play speeds [N] (default: cfg.speed for every lane), or per-lane speed
+    SCHEDULES [N, rows]: the answers to each lane's successive get_next_speed() calls.
     Returns (steps[N,V] STEP_DTYPE, bw[N,V], final[N] FINAL_DTYPE, total_ticks)."""
     flat, off, lens = pack_traces(traces)
     trace_id = np.ascontiguousarray(trace_id, np.int32)
@@ -112,7 +115,15 @@ def env_batch(cfg, traces, trace_id, offset, actions, max_ticks=1 << 40, speeds=
     bw = np.zeros((N, V), np.float64)
     fin = np.zeros(N, FINAL_DTYPE)
     sp = steps.ctypes.data_as(C.c_void_p) if want_steps else None
-    if speeds is not None:
+    if speeds is not None and np.ndim(speeds) == 2:
+        speeds = np.ascontiguousarray(speeds, np.float64)
+        assert speeds.shape[0] == N
+        rc = lib().oracle_env_batch_sched(
+            C.byref(cfg), _p(flat, C.c_double), _p(off, C.c_int64), _p(lens, C.c_int32),
+            _p(trace_id, C.c_int32), _p(offset, C.c_int32), _p(actions, C.c_int32),
+            _p(speeds, C.c_double), C.c_int32(speeds.shape[1]), C.c_int32(N), sp,
+            _p(bw, C.c_double), fin.ctypes.data_as(C.c_void_p), C.c_int64(max_ticks))
+    elif speeds is not None:
         speeds = np.ascontiguousarray(speeds, np.float64)
         assert speeds.shape == (N,)
         rc = lib().oracle_env_batch_speeds(

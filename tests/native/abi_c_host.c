@@ -20,7 +20,8 @@
 
 /* mirrors of the oracle's structs (oracle/abr_oracle.c) */
 typedef struct { int32_t n_rates, video_length; double chunk_length, max_buffer, start_up_length,
-                 interval, wr, wv, ws, wl, speed, ladder[16]; const double *br_table; } ocfg;
+                 interval, wr, wv, ws, wl, speed, ladder[16]; const double *br_table;
+                 const double *speed_sched; int32_t speed_rows; int64_t speed_stride; } ocfg;
 typedef struct { double qoe, rebuffer_time, start_up_time, average_latency, global_time,
                  buffer_level, play_time; int64_t ticks; int32_t play_id, chunk_id; } ofin;
 typedef int64_t (*obatch_fn)(const ocfg *, const double *, const int64_t *, const int32_t *,

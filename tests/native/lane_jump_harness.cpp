@@ -25,6 +25,7 @@ void *lj_create(double interval, double L, double speed, int32_t V, double max_b
     c->t.avail_tick = c->tt.avail_tick.data();
     c->t.L = L; c->t.sd = c->tt.sd; c->t.max_buffer = max_buffer; c->t.start_up_length = start_up_length;
     c->t.V = V; c->t.max_ticks = max_ticks; c->t.per_lane_speed = false;
+    c->t.speed_rows = 0; c->t.speed_stride = 0; c->t.speeds = nullptr;
     c->n_rates = n_rates;
     for (int i = 0; i < n_rates; i++) c->ladder[i] = ladder[i];
     return c;
@@ -36,14 +37,18 @@ void lj_destroy(void *h) { delete (Ctx *)h; }
 //                 last_bw, sumk (as double), flags(su|be<<1|bf<<2)
 // fin[0..5] = global_time, rebuffer_time, start_up_time, play_time, buffer_level, sumk; fin_i[0]=n_play
 // returns 0, or -2 on timeout
+// sched != NULL: a speed schedule of `rows` values for this lane (played chunk p plays at
+// sched[min(p, rows - 1)]); fin_i[1] then returns play_id
 int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const int32_t *actions,
-               double *rec, double *bw_out, double *fin, int32_t *fin_i, double lane_speed) {
+               double *rec, double *bw_out, double *fin, int32_t *fin_i, double lane_speed,
+               const double *sched, int32_t rows) {
     Ctx *c = (Ctx *)h;
     abrx::Tables t = c->t;
     abrx::LaneJ s;
     s.cur.trace = trace; s.cur.tlen = tlen;
     s.sd = t.sd;
     if (lane_speed > 0.0) { t.per_lane_speed = true; s.sd = lane_speed * 0.01; }   // :182 product
+    if (sched) { t.per_lane_speed = true; t.speed_rows = rows; t.speed_stride = 1; t.speeds = sched; s.lane = 0; }
     abrx::lanej_init(s, t, offset);
     if (!abrx::lanej_wait_call(s, t)) return -2;
     double last_bw = 0.0;
@@ -64,21 +69,23 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
     fin[3] = t.per_lane_speed ? s.pt : c->tt.GP[s.n_play];
     fin[4] = s.buf; fin[5] = (double)s.sumk;
     fin_i[0] = s.n_play;
+    if (sched) { fin_i[1] = s.play_id; fin[5] = s.pt_sum; }
     return 0;
 }
 
 int64_t lj_batch(void *h, const double *traces, const int64_t *trace_off, const int32_t *trace_len,
                  const int32_t *trace_id, const int32_t *offset, const int32_t *actions,
                  int32_t n_lanes, double *rec, double *bw_out, double *fin, int32_t *fin_i,
-                 const double *speeds /* nullable: per-lane play speeds */) {
+                 const double *speeds /* nullable: per-lane play speeds */,
+                 const double *sched /* nullable: [n_lanes][rows] speed schedules */, int32_t rows) {
     Ctx *c = (Ctx *)h;
     const int V = c->t.V;
     for (int32_t i = 0; i < n_lanes; i++) {
         int tid = trace_id[i];
         int rc = lj_episode(h, traces + trace_off[tid], trace_len[tid], offset[i],
                             actions + (size_t)i * V, rec + (size_t)i * V * 8,
-                            bw_out + (size_t)i * V, fin + (size_t)i * 6, fin_i + i,
-                            speeds ? speeds[i] : 0.0);
+                            bw_out + (size_t)i * V, fin + (size_t)i * 6, fin_i + (size_t)i * 2,
+                            speeds ? speeds[i] : 0.0, sched ? sched + (size_t)i * rows : nullptr, rows);
         if (rc) return -(1000 + (int64_t)i * 10 - rc);
     }
     return 0;

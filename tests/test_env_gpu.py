@@ -334,6 +334,74 @@ def test_per_lane_speeds(oracle):
         make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N, impl="tick")
 
 
+@pytest.mark.parametrize("impl", ["split", "jump"])
+def test_speed_schedule_matches_reference_golden(impl):
+    """8f rank 3, second half: the play speed is re-read at every played chunk
+    (Simulator.py:176-177).  The fixture is the reference driven by a scripted speed
+    controller; every call-site frame is compared, incl. play_id / play_length."""
+    m, g = load_golden("env_speed_schedule")
+    N, V = g["actions"].shape
+    sched = torch.from_numpy(g["speed_sched"].T.copy())          # [rows, N]
+    env = make_env(dict(m, speed=sched), g["traces"], N, impl=impl)
+    obs = env.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
+    acts = torch.from_numpy(g["actions"]).cuda()
+    for s in range(V):
+        _cmp_step(env.observe_f64(), g, s, "env_speed_schedule")
+        assert np.array_equal(obs.cpu().numpy()[5], g["play_time"][:, s].astype(np.float32))
+        obs, _, _ = env.step(acts[:, s].contiguous())
+    f = env.observe_f64()
+    for k in ["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]:
+        assert np.array_equal(f[k].cpu().numpy(), g["final_" + k]), k
+    assert np.allclose(f["average_latency"].cpu().numpy(), g["final_average_latency"], rtol=LAT_RTOL)
+    assert np.array_equal(f["play_id"].cpu().numpy().astype(np.int32), g["final_play_id"])
+    assert np.allclose(env.episode_qoe().cpu().numpy(), g["final_qoe"], rtol=1e-10)
+    assert np.array_equal(env.history()[1].cpu().numpy().T, g["final_bandwidths"])
+
+
+def test_speed_schedule_fused_and_simulator_class(oracle):
+    """Schedules under the fused random rollout with auto-reset (the schedule restarts with the
+    episode), and through the Simulator class with a speed controller that answers tensors."""
+    import abrsimulator_amd as A
+    meta, traces, trace_id, offset, _ = _random_case(seed=61, N=320, V=9, max_buffer=12.0)
+    N, V, SEED = 320, 9, 77
+    rng = np.random.default_rng(61)
+    sched = rng.choice([0.6, 0.8, 1.0, 1.2, 1.5, 1.9], (5, N))
+    env = make_env(dict(meta, speed=torch.from_numpy(sched)), traces, N, auto_reset=True)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    out = env.step_random(2 * V, SEED)
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
+                         meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+    for ep in range(2):
+        a = out["actions"].cpu().numpy()[ep * V:(ep + 1) * V].T.copy()
+        steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, a, speeds=sched.T.copy())
+        o = out["obs"].cpu().numpy()[ep * V:(ep + 1) * V]
+        for s in range(V - 1):
+            assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), (ep, s)
+            assert np.array_equal(o[s, 5], steps["play_time"][:, s + 1].astype(np.float32)), (ep, s)
+    assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+
+    class Replay:
+        def get_next_bitrate(self, chunk_id, previous_bitrates, previous_bandwidths, buffer_level):
+            return acts[:, int(chunk_id[0])]
+
+    class Speed:
+        def __init__(self):
+            self.calls = 0
+
+        def get_next_speed(self):
+            self.calls += 1
+            return torch.from_numpy(sched[min(self.calls - 1, 4)])
+
+    acts = torch.from_numpy(a).cuda()
+    sim = A.Simulator(Replay(), Speed(), n_lanes=N)
+    sim.set_qoe_metric(A.QOEMetric(*meta["weights"]))
+    sim.set_network_info(meta["interval"], A.NetworkInfo(meta["interval"], traces))
+    sim.set_mpd(meta["chunk_length"], meta["max_buffer"], meta["start_up_length"],
+                A.MPD(V, meta["chunk_length"], meta["max_buffer"], meta["start_up_length"], A.Chunk(meta["ladder"])))
+    sim.set_lanes(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    assert np.allclose(sim.run().cpu().numpy(), fin["qoe"], rtol=1e-10)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_configurations_against_oracle(oracle, seed):
     """Config-space fuzz on the device (the CPU twin of this test runs 60 seeds through the

@@ -28,7 +28,8 @@ def H():
     return lib
 
 
-def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0, speeds=None):
+def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0, speeds=None, sched=None):
+    """sched: optional [N, rows] per-lane speed schedules (played chunk p plays at sched[i, min(p, rows-1)])."""
     from oracle.oracle import pack_traces
     ladder = np.asarray(meta["ladder"], np.float64)
     V = meta["video_length"]
@@ -42,15 +43,20 @@ def run_jump(H, meta, traces, trace_id, offset, actions, max_ticks=0, speeds=Non
     trace_id = np.ascontiguousarray(trace_id, np.int32); offset = np.ascontiguousarray(offset, np.int32)
     actions = np.ascontiguousarray(actions, np.int32)
     N = actions.shape[0]
-    rec = np.zeros((N, V, 8)); bw = np.zeros((N, V)); fin = np.zeros((N, 6)); fin_i = np.zeros(N, np.int32)
+    rec = np.zeros((N, V, 8)); bw = np.zeros((N, V)); fin = np.zeros((N, 6)); fin_i = np.zeros((N, 2), np.int32)
+    if sched is not None:
+        sched = np.ascontiguousarray(sched, np.float64)
+        assert sched.shape[0] == N
     P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     rc = H.lj_batch(C.c_void_p(h), P(flat, C.c_double), P(off, C.c_int64), P(lens, C.c_int32),
                     P(trace_id, C.c_int32), P(offset, C.c_int32), P(actions, C.c_int32), C.c_int32(N),
                     P(rec, C.c_double), P(bw, C.c_double), P(fin, C.c_double), P(fin_i, C.c_int32),
-                    P(np.ascontiguousarray(speeds, np.float64), C.c_double) if speeds is not None else None)
+                    P(np.ascontiguousarray(speeds, np.float64), C.c_double) if speeds is not None else None,
+                    P(sched, C.c_double) if sched is not None else None,
+                    C.c_int32(sched.shape[1] if sched is not None else 0))
     H.lj_destroy(C.c_void_p(h))
     assert rc == 0, rc
-    return rec, bw, fin, fin_i
+    return rec, bw, fin, (fin_i if sched is not None else fin_i[:, 0])
 
 
 def _check(rec, bw, fin, steps, bwo, fino, sd=0.01):
@@ -174,3 +180,43 @@ def test_random_configurations_against_oracle(H, oracle, seed):
     rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions,
                                    max_ticks=int(fino["ticks"].max()) + 1000)
     _check(rec, bw, fin, steps, bwo, fino)
+
+
+def test_speed_schedule_golden_bit_exact(H):
+    """The event-driven lane logic with a speed that changes at every played chunk, against the
+    reference run with a scripted get_next_speed() (tests/golden/env_speed_schedule)."""
+    m, g = load_golden("env_speed_schedule")
+    rec, bw, fin, fin_i = run_jump(H, m, list(g["traces"]), g["trace_id"], g["offset"], g["actions"],
+                                   sched=g["speed_sched"])
+    names = ["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]
+    for c, k in enumerate(names):
+        assert np.array_equal(rec[:, :, c], g[k]), k
+    assert np.array_equal(rec[:, :, 5], g["arg_last_bandwidth"])
+    assert np.array_equal(bw, g["final_bandwidths"])
+    for c, k in enumerate(names):
+        assert np.array_equal(fin[:, c], g["final_" + k]), k
+    assert np.array_equal(fin_i[:, 1], g["final_play_id"])
+    # (average_latency from the carried sums is checked on the device path, tests/test_env_gpu.py)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_speed_schedule_against_oracle(H, oracle, seed):
+    rng = np.random.default_rng(seed)
+    meta = dict(ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=float(rng.choice([2.0, 4.0, 1.0])),
+                video_length=14, max_buffer=float(rng.choice([20.0, 6.0])), start_up_length=4.0,
+                interval=float(rng.choice([1.0, 0.5])), weights=[4.3, 1, 1, 0.1], speed=1.0)
+    N, rows = 300, int(rng.integers(2, 9))
+    traces = [rng.uniform(0.3, 7.0, 1500).astype(np.float32).astype(np.float64) for _ in range(5)]
+    trace_id = rng.integers(0, 5, N).astype(np.int32)
+    offset = rng.integers(0, 1500, N).astype(np.int32)
+    actions = rng.integers(0, 6, (N, 14)).astype(np.int32)
+    sched = rng.choice([0.5, 0.75, 0.8, 1.0, 1.1, 1.25, 1.5, 2.0, 0.9173], (N, rows))
+    cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], 14, meta["max_buffer"], 4.0, meta["interval"],
+                         meta["weights"], 1.0)
+    steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, speeds=sched)
+    rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions, sched=sched)
+    for c, k in enumerate(["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]):
+        assert np.array_equal(rec[:, :, c], steps[k]), k
+        assert np.array_equal(fin[:, c], fino[k]), k
+    assert np.array_equal(bw, bwo)
+    assert np.array_equal(fin_i[:, 1], fino["play_id"])

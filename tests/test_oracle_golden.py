@@ -40,6 +40,28 @@ def test_env_episode_bit_exact(oracle, name):
     assert ticks > 0
 
 
+def test_env_speed_schedule_bit_exact(oracle):
+    """A scripted speed controller: get_next_speed() answers differently at every played chunk
+    (Simulator.py:176-177).  The fixture is the reference itself driven by that script."""
+    m, g = load_golden("env_speed_schedule")
+    cfg = _env_cfg(oracle, m)
+    steps, bw, fin, _ = oracle.env_batch(cfg, list(g["traces"]), g["trace_id"], g["offset"],
+                                         g["actions"], speeds=g["speed_sched"])
+    for k in ["global_time", "rebuffer_time", "start_up_time", "play_time", "average_latency",
+              "buffer_level", "play_length", "instant_latency"]:
+        assert np.array_equal(steps[k], g[k]), k
+    for k in ["chunk_id", "play_id", "start_up", "buffer_empty", "buffer_full"]:
+        assert np.array_equal(steps[k], g[k]), k
+    assert np.array_equal(bw, g["final_bandwidths"])
+    for k in ["qoe", "rebuffer_time", "start_up_time", "average_latency", "global_time",
+              "buffer_level", "play_time"]:
+        assert np.array_equal(fin[k], g["final_" + k]), k
+    assert np.array_equal(fin["play_id"], g["final_play_id"])
+    # the script really was consumed past its end (the last answer repeats) and speeds differ
+    assert g["final_speed_calls"].min() > g["speed_sched"].shape[1]
+    assert len(np.unique(g["speed_sched"])) > 8
+
+
 def test_env_golden_exercises_the_edges():
     """The fixtures must actually contain the regimes they are named for."""
     _, g = load_golden("env_bufferfull_i05")

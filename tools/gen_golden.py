@@ -106,10 +106,24 @@ class ConstSpeed:
         return self.s
 
 
-def run_lane(S, cfg, trace, actions, tmpdir):
+class ScheduleSpeed:
+    """A speed controller with a script: the p-th get_next_speed() call (one per played chunk,
+    Simulator.py:176-177) answers schedule[min(p, len - 1)]."""
+
+    def __init__(self, schedule):
+        self.schedule, self.calls = list(schedule), 0
+
+    def get_next_speed(self):
+        v = self.schedule[min(self.calls, len(self.schedule) - 1)]
+        self.calls += 1
+        return v
+
+
+def run_lane(S, cfg, trace, actions, tmpdir, schedule=None):
     """One reference episode. Returns (per-step records, final dict)."""
     abr = RecordingAbr(actions)
-    sim = S.Simulator(abr, ConstSpeed(cfg["speed"]))
+    spd = ScheduleSpeed(schedule) if schedule is not None else ConstSpeed(cfg["speed"])
+    sim = S.Simulator(abr, spd)
     sim.set_qoe_metric(S.QOEMetric(*cfg["weights"]))
     # trace goes through the reference's own loader (Simulator.py:59-65)
     path = os.path.join(tmpdir, "trace.txt")
@@ -139,6 +153,8 @@ def run_lane(S, cfg, trace, actions, tmpdir):
 
     sim.calculate_qoe = spy
     final["qoe"] = float(sim.run())
+    if schedule is not None:
+        final["speed_calls"] = spd.calls
     return abr.rec, final
 
 
@@ -173,6 +189,12 @@ ENV_CONFIGS = {
         ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=12,
         max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1],
         speed=1.0, lanes=16, n_traces=4, trace_len=1000, bw=(0.2, 6.0), policy="const"),
+    # a speed controller that answers differently at every played chunk (Simulator.py:176-177)
+    "env_speed_schedule": dict(
+        ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4, video_length=20,
+        max_buffer=20, start_up_length=8, interval=1.0, weights=[4.3, 1, 1, 0.1],
+        speed=1.0, lanes=24, n_traces=4, trace_len=1000, bw=(0.3, 6.0), policy="random",
+        speed_schedule=[1.0, 1.25, 0.8, 1.1, 0.9, 1.5, 0.75, 1.0, 1.3, 0.85, 1.2, 0.95]),
     # chunk_length 3 with interval 0.7: neither divides exactly
     "env_l3_i07": dict(
         ladder=[0.5, 1.0, 2.0, 3.5], chunk_length=3, video_length=20,
@@ -204,11 +226,22 @@ def gen_env(name, cfg, S):
     fin = {"final_" + k: np.zeros(N, np.float64) for k in fin_f}
     fin["final_play_id"] = np.zeros(N, np.int32)
     fin["final_bandwidths"] = np.zeros((N, V), np.float64)
+    sched = None
+    if "speed_schedule" in cfg:
+        # each lane gets its own rotation / sub-sampling of the script, some with fewer rows
+        base = cfg["speed_schedule"]
+        rows = len(base)
+        sched = np.array([[base[(i + (1 + i % 3) * p) % rows] for p in range(rows)] for i in range(N)],
+                         dtype=np.float64)
+        fin["final_speed_calls"] = np.zeros(N, np.int32)
     with tempfile.TemporaryDirectory() as td:
         for i in range(N):
             t = traces[trace_id[i]]
             rot = np.concatenate([t[offset[i]:], t[:offset[i]]])
-            rec, final = run_lane(S, cfg, rot, [int(a) for a in actions[i]], td)
+            rec, final = run_lane(S, cfg, rot, [int(a) for a in actions[i]], td,
+                                  schedule=None if sched is None else [float(v) for v in sched[i]])
+            if sched is not None:
+                fin["final_speed_calls"][i] = final["speed_calls"]
             assert len(rec) == V and final["chunk_id"] == V
             assert final["bitrates"] == [int(a) for a in actions[i]]
             # D7: the fixture must stay inside the non-wrapping domain
@@ -221,6 +254,8 @@ def gen_env(name, cfg, S):
                 fin["final_" + k][i] = final[k]
             fin["final_play_id"][i] = final["play_id"]
             fin["final_bandwidths"][i] = final["bandwidths"]
+    if sched is not None:
+        out["speed_sched"] = sched
     meta = {k: v for k, v in cfg.items() if k not in ("bw",)}
     meta["bw_range"] = list(cfg["bw"])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), traces=traces, trace_id=trace_id,
@@ -392,9 +427,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if a.only in ("", "mpc") or a.only.startswith("mpc_"):
         gen_mpc(load_mpc(), a.only if a.only.startswith("mpc_") else "")
-    if a.only in ("", "env"):
+    if a.only in ("", "env") or a.only.startswith("env_"):
         S = load_simulator_repaired()
         for name, cfg in ENV_CONFIGS.items():
+            if a.only.startswith("env_") and name != a.only:
+                continue
             gen_env(name, cfg, S)
 
 
