@@ -304,6 +304,21 @@ __device__ inline void write_obs(const Lane &s, const EnvParams &p, int64_t i, f
     obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
 }
 
+// previous_bitrates of the episode that just ended, kept for K4 under auto_reset.  Eight
+// independent loads in flight per trip: a plain load -> store loop pays one memory latency per
+// chunk (48 of them per episode end, measured 0.9 k cycles per decision).
+__device__ inline void copy_episode_actions(const EnvParams &p, int64_t i, int32_t V) {
+    int c = 0;
+    for (; c + 8 <= V; c += 8) {
+        uint8_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p.action_hist[(int64_t)(c + u) * p.n_lanes + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p.ep_actions[(int64_t)(c + u) * p.n_lanes + i] = v[u];
+    }
+    for (; c < V; c++) p.ep_actions[(int64_t)c * p.n_lanes + i] = p.action_hist[(int64_t)c * p.n_lanes + i];
+}
+
 // MODE 0: reset (fresh lanes run to their first call site)
 // MODE 1: step  (one externally supplied action per lane)
 // MODE 2: fused random-policy rollout of n_steps decisions per lane
@@ -397,9 +412,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                     p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
                     if (p.auto_reset && ended) {
                         // re-arm: this step's obs is the new episode's first call site
-                        for (int c = 0; c < V; c++)
-                            p.ep_actions[(int64_t)c * p.n_lanes + i] =
-                                p.action_hist[(int64_t)c * p.n_lanes + i];
+                        copy_episode_actions(p, i, V);
                         lane_init(s, p, offset0);
                         episode_no++;
                         n_su_obs = 0; n_rb_obs = 0;
@@ -686,9 +699,7 @@ __global__ __launch_bounds__(64) void env_jump_kernel(
                                                  : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
-                            for (int c = 0; c < V; c++)
-                                p.ep_actions[(int64_t)c * p.n_lanes + i] =
-                                    p.action_hist[(int64_t)c * p.n_lanes + i];
+                            copy_episode_actions(p, i, V);
                             abrx::lanej_init(s, tb, offset0);
                             episode_no++;
                             n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
@@ -812,6 +823,9 @@ __device__ __forceinline__ void split_role_download(
         ABR_STAMP(0);
         if (d_alive && d_step < n_total) {
             snap_j = cur.j; snap_tpos = cur.tpos;
+            // (issuing these loads one iteration ahead, before the barrier, was measured on the
+            // same box: 1.6 % SLOWER -- 450.5 vs 443.9 us per launch -- the 19 extra live
+            // registers cost more than the hidden latency; profiles/r02_ab_prefetch.txt)
             const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
             ABR_STAMP(1);
             int32_t a;
@@ -951,9 +965,7 @@ __device__ __forceinline__ void split_role_player(
                                                  : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
-                            for (int c = 0; c < V; c++)
-                                p.ep_actions[(int64_t)c * p.n_lanes + i] =
-                                    p.action_hist[(int64_t)c * p.n_lanes + i];
+                            copy_episode_actions(p, i, V);
                             abrx::lanej_init_player(s, tb);
                             episode_no++;
                             n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;

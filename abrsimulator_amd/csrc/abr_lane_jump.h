@@ -267,18 +267,34 @@ ABR_HD int32_t trace_wrap(int32_t pos, int32_t tlen) {
     return pos;
 }
 
-ABR_HD StepStart lanej_begin_step(Cursor &s, const Tables &t, int32_t k, int32_t chunk_id) {
+// The loads of lanej_begin_step on their own, so that a caller can issue them well before it
+// needs the values (the role-split kernel issues them before its workgroup barrier).
+struct StepLoads {
     int32_t ke[kCatch + 2];
     double bw[kCatch + 2];
+    int32_t avail_next;
+};
+
+ABR_HD StepLoads lanej_begin_load(const Cursor &s, const Tables &t, int32_t chunk_id) {
+    StepLoads ld;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < kCatch + 2; i++) {
-        ke[i] = t.interval_tick[s.j + 1 + i];
-        bw[i] = s.trace[trace_wrap(s.tpos + i, s.tlen)];
+        ld.ke[i] = t.interval_tick[s.j + 1 + i];
+        ld.bw[i] = s.trace[trace_wrap(s.tpos + i, s.tlen)];
     }
+    ld.avail_next = t.avail_tick[chunk_id + 1];
+    return ld;
+}
+
+// ... and the selection among them once the call-site tick k is known.  The cursor must be the
+// one the loads were issued for.
+ABR_HD StepStart lanej_begin_select(Cursor &s, const Tables &t, const StepLoads &ld, int32_t k) {
+    const int32_t *ke = ld.ke;
+    const double *bw = ld.bw;
     StepStart st;
-    st.avail_next = t.avail_tick[chunk_id + 1];
+    st.avail_next = ld.avail_next;
     // intervals the cursor is behind: ke[] is non-decreasing
     int32_t adv = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -315,6 +331,11 @@ ABR_HD StepStart lanej_begin_step(Cursor &s, const Tables &t, int32_t k, int32_t
     st.c = c_bw * kTickDt; st.bw_next = n_bw; st.ke = c_ke; st.ke_next = n_ke;
     st.tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
     return st;
+}
+
+ABR_HD StepStart lanej_begin_step(Cursor &s, const Tables &t, int32_t k, int32_t chunk_id) {
+    const StepLoads ld = lanej_begin_load(s, t, chunk_id);
+    return lanej_begin_select(s, t, ld, k);
 }
 
 // Phase A of one decision: the download side.  Needs nothing of the player state but
