@@ -37,7 +37,13 @@
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
-constexpr int kPrologue = 16;       // plain additions at the start of a download (see lanej_step)
+#ifndef ABR_K_PROLOGUE
+#define ABR_K_PROLOGUE 16
+#endif
+#ifndef ABR_K_DRAIN_TAIL
+#define ABR_K_DRAIN_TAIL 16
+#endif
+constexpr int kPrologue = ABR_K_PROLOGUE;   // plain additions at the start of a download (see lanej_download)
 
 struct Tables {
     const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
@@ -114,9 +120,11 @@ ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
 // buffer_level -= speed*dt per playing tick (:184) for up to m ticks, stopping right after the
 // first result <= 0 (:194).  Same contract as chain<STOP_LE>(b, -sd, 0.0, m, a).  Far from
 // zero the exact jumps do the work; within kDrainTail ticks of zero a binade lasts only a
-// few ticks (32, 16, 8, ...: one segment each), so the last stretch is plain subtractions --
-// the reference's own sequence.  The switch point affects speed only, never a result.
-constexpr int kDrainTail = 64;
+// few ticks (8, 4, 2, 1: one segment each), so the last stretch is plain subtractions -- the
+// reference's own sequence.  The switch point affects speed only, never a result; measured
+// on one MI355X box at 65 536 lanes (profiles/r02_ab_drain_tail.txt): 8-32 ticks are
+// equivalent (7.3-7.4e9 env-steps/s), 64 costs 5 %, 128 costs 20 %.
+constexpr int kDrainTail = ABR_K_DRAIN_TAIL;
 ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     ChainState cs;
     cs.x = b_io; cs.d = 0.0; cs.inb = 0;
