@@ -137,7 +137,8 @@ struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
-    int impl;   // 2 = role-split event-driven kernels (default), 0 = one thread per lane,
+    int impl;   // 3 = auto (default): role-split up to kSplitMaxLanes lanes, one thread per lane above;
+                // 2 = role-split event-driven kernels, 0 = event-driven, one thread per lane,
                 // 1 = tick-by-tick kernels (cross-check)
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds / _speed_schedule: latched by the next full reset
@@ -1217,7 +1218,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     if (!e) return fail(ABR_E_INVALID, "out of host memory");
     memset(e, 0, sizeof(*e));
     e->cfg = *cfg;
-    e->impl = 2;
+    e->impl = 3;
     e->workspace_bytes = L.total;
     EnvParams &p = e->p;
     p.n_rates = cfg->n_rates; p.video_length = cfg->video_length; p.max_ticks = mt;
@@ -1278,7 +1279,7 @@ extern "C" int abr_env_destroy(abr_env *env) {
 // 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl < 0 || impl > 2) return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick) or 2 (split)");
+    if (impl < 0 || impl > 3) return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split) or 3 (auto)");
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -1327,6 +1328,15 @@ extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
 
 static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 
+// The role-split kernels win while the one-thread-per-lane form would leave SIMDs with one or two
+// waves (65 536 lanes: 7.2e9 vs 6.2e9 env-steps/s); from 262 144 lanes on the plain form has
+// enough waves of its own and no barrier (1.39e10 vs 1.32e10 at 1 M).  profiles/r02_sweeps.txt
+constexpr int64_t kSplitMaxLanes = 131072;
+static inline int effective_impl(const abr_env *env) {
+    if (env->impl != 3) return env->impl;
+    return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
+}
+
 extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
                              const int32_t *start_offset_dev, const uint8_t *lane_mask_dev,
                              float *obs_out_dev, void *stream) {
@@ -1358,12 +1368,13 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
                             float *reward_out_dev, uint8_t *done_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
-    if (env->impl == 2)
+    const int impl = effective_impl(env);
+    if (impl == 2)
         hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
                            (hipStream_t)stream, env->p, actions_dev, obs_out_dev, reward_out_dev,
                            done_out_dev, nullptr, 1, 0ull);
     else
-        hipLaunchKernelGGL(env->impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+        hipLaunchKernelGGL(impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                            (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
                            obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull);
     HIP_TRY(hipGetLastError());
@@ -1375,12 +1386,13 @@ extern "C" int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed,
                                    uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
-    if (env->impl == 2)
+    const int impl = effective_impl(env);
+    if (impl == 2)
         hipLaunchKernelGGL(env_split_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
                            (hipStream_t)stream, env->p, nullptr, obs_out_dev, reward_out_dev,
                            done_out_dev, actions_out_dev, n_steps, seed);
     else
-        hipLaunchKernelGGL(env->impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
+        hipLaunchKernelGGL(impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                            (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
                            obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
     HIP_TRY(hipGetLastError());
@@ -1941,7 +1953,7 @@ extern "C" int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg,
         float *obs = obs_out_dev ? obs_out_dev + (int64_t)s * ABR_OBS_DIM * N : nullptr;
         float *rew = reward_out_dev ? reward_out_dev + (int64_t)s * N : nullptr;
         uint8_t *dn = done_out_dev ? done_out_dev + (int64_t)s * N : nullptr;
-        if (env->impl == 2)
+        if (effective_impl(env) == 2)
             hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(N)), dim3(128), 0, st, env->p, act, obs, rew,
                                dn, nullptr, 1, 0ull);
         else

@@ -43,7 +43,7 @@ class BatchedABREnv:
 
     def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
                  device="cuda", speed=1.0, auto_reset: bool = False, max_ticks: int = 0,
-                 lane_id_base: int = 0, impl: str = "split"):
+                 lane_id_base: int = 0, impl: str = "auto"):
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -113,10 +113,11 @@ class BatchedABREnv:
         self._h = h
         if lane_id_base:
             _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
-        impls = {"jump": 0, "tick": 1, "split": 2}
+        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3}
         if impl not in impls:
-            raise ValueError("impl must be 'split' (role-split event-driven kernels, default), "
-                             "'jump' (event-driven, one thread per lane) or 'tick'")
+            raise ValueError("impl must be 'auto' (default: 'split' up to 131 072 lanes, 'jump' above), "
+                             "'split' (role-split event-driven kernels), 'jump' (event-driven, one "
+                             "thread per lane) or 'tick'")
         self.impl = impl
         _lib.check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:

@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--impl", default="split", choices=["split", "jump", "tick"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "split", "jump", "tick"])
     ap.add_argument("--min-timed-steps", type=int, default=960,
                     help="when --steps is smaller than this the timed region of exactly --steps steps is "
                          "repeated (each repeat bracketed by barrier + synchronize) and the MEDIAN repeat "
@@ -253,8 +253,9 @@ def main():
     env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
                           auto_reset=True, lane_id_base=lane0, impl=a.impl)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    impl = a.impl if a.impl != "auto" else ("split" if N <= 131072 else "jump")   # what "auto" resolves to
     env_kernel = {"split": "env_split_kernel<2>", "jump": "env_jump_kernel<2>",
-                  "tick": "env_advance_kernel<2>"}[a.impl]
+                  "tick": "env_advance_kernel<2>"}[impl]
 
     def barrier():
         if world > 1:
@@ -436,7 +437,7 @@ def main():
         ev2 = []
         player, ctl, hn0, hs0 = mpc_setup()
         run2 = mpc_runner(player, ctl, hn0, hs0, ev2, False)
-        K2, W2 = 30, 5
+        K2, W2 = 100, 20
         run2(W2, False)
         el2 = timed_region(run2, K2)
         ls2, _ = launch_stats(ev2)
@@ -461,7 +462,7 @@ def main():
             "scaling": "strong" if a.total_lanes else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": repeats, "repeat_seconds": times,
             "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
-                       "fuse": F, "impl": a.impl,
+                       "fuse": F, "impl": impl,
                        "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
                        "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
                        "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",

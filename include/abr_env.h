@@ -152,11 +152,12 @@ int abr_env_set_speed_schedule(abr_env *env, const double *speeds_dev, int32_t n
  * chunk's ladder.  Latched like abr_env_set_lane_speeds: picked up by the next reset of ALL lanes. */
 int abr_env_set_bitrate_table(abr_env *env, const double *br_table_dev);
 
-/* Which kernels serve reset/step: 2 (default) = event-driven (exact closed-form stepping
- * of the float64 tick sequences) with each lane's download side and player side on two
- * waves of one workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per
- * 0.01 s tick.  All three produce identical state and outputs (the workspace is
- * interchangeable between them); 0 and 1 exist as independent cross-checks. */
+/* Which kernels serve reset/step: 2 = event-driven (exact closed-form stepping of the
+ * float64 tick sequences) with each lane's download side and player side on two waves of one
+ * workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per 0.01 s tick;
+ * 3 (default) = 2 up to 131 072 lanes, 0 above (whichever is faster at that size).  All
+ * produce identical state and outputs (the workspace is interchangeable between them);
+ * 1 exists as an independent cross-check. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 
 /*

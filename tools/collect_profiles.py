@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the round's evidence from gpurun_out/ (scratch, written by tools/gpu_final.sh on the
-GPU box) into profiles/ (tracked): rocprofv3 kernel stats, PMC summaries, bench JSON lines."""
+"""Summarise the round's evidence from gpurun_out/r02/ (scratch, written by tools/gpu_r02_final.sh on
+the GPU box) into profiles/ (tracked): rocprofv3 kernel stats, PMC summaries, bench JSON lines.
+
+  python tools/collect_profiles.py --stage DIR   on the GPU box: DIR/*/.../*.csv -> DIR/summary.json
+  python tools/collect_profiles.py               here: gpurun_out/r02/ -> profiles/r02_*
+"""
+import argparse
 import collections
 import csv
 import glob
@@ -9,63 +14,111 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-TAG = "r01"
-F = 48
+TAG = "r02"
+ENV_KERNEL = "env_split_kernel<2>"
+MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
+LANES, FUSE = 65536, 48
 
-def cp(src_glob, dst):
-    src = sorted(glob.glob(os.path.join(G, src_glob)))[-1]
-    shutil.copy(src, os.path.join(P, dst))
 
-cp("profile_r01b_env/stats/*/*_kernel_stats.csv", f"{TAG}_env_random_fuse{F}_kernel_stats.csv")
-cp("profile_r01b_mpc/stats/*/*_kernel_stats.csv", f"{TAG}_mpc_kernel_stats.csv")
-cp("profile_r01b_env/summary.json", f"{TAG}_env_random_fuse{F}_pmc_summary.json")
-cp("profile_r01b_mpc/summary.json", f"{TAG}_mpc_pmc_summary.json")
-cp("bench_final.json", f"{TAG}_bench_default.json")
-cp("bench_final_mpc.json", f"{TAG}_bench_mpc.json")
-cp("bench_final_env_mpc.json", f"{TAG}_bench_env_mpc.json")
-cp("sweep_final.log", f"{TAG}_sweeps.txt")
-
-out = {}
-for d in sorted(glob.glob(os.path.join(G, "pmc_r01b/g*/"))):
-    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[-1:]:
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+def counters(path):
+    """{kernel: {counter: (mean, n)}} over every dispatch of a --pmc run."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items():
-            if "env_jump_kernel<2>" in k:
-                out.update({c: sum(x) / len(x) for c, x in v.items()})
-json.dump({"kernel": "env_jump_kernel<2>",
-           "config": f"65536 lanes, fuse {F} (one launch = {F} decisions per lane), 1024 waves",
-           "per_launch_average": out,
-           "derived": {
-               "valu_insts_per_wave_per_decision": out["SQ_INSTS_VALU"] / 1024 / F,
-               "salu_insts_per_wave_per_decision": out["SQ_INSTS_SALU"] / 1024 / F,
-               "vmem_rd_insts_per_wave_per_decision": out["SQ_INSTS_VMEM_RD"] / 1024 / F,
-               "wave_cycles_per_decision": out["SQ_WAVE_CYCLES"] * 4 / 1024 / F,
-               "wait_fraction": out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"],
-               "active_fraction": out["SQ_ACTIVE_INST_ANY"] / out["SQ_WAVE_CYCLES"],
-               "avg_active_lanes_per_valu_inst": out["SQ_THREAD_CYCLES_VALU"] / out["SQ_ACTIVE_INST_VALU"]}},
-          open(os.path.join(P, f"{TAG}_env_jump_sq_counters.json"), "w"), indent=1)
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
 
-d = json.load(open(os.path.join(G, "profile_r01b_env/summary.json")))
-f, nf = d["FETCH_SIZE_KB"]["void env_jump_kernel<2>"]
-w, nw = d["WRITE_SIZE_KB"]["void env_jump_kernel<2>"]
-m = json.load(open(os.path.join(G, "profile_r01b_mpc/summary.json")))
-km = [k for k in m["FETCH_SIZE_KB"] if "mpc_select" in k][0]
-fm, wm = m["FETCH_SIZE_KB"][km][0], m["WRITE_SIZE_KB"][km][0]
-src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_profile.sh), "
-       "per-launch averages; FETCH_SIZE doubled (gfx950 reports half of a coalesced read, "
-       "MI355X_MICROARCH.md 'HBM'; our 4-8 B/lane reads are outside the calibrated 16 B/lane case, "
-       "so the read side is an upper estimate), WRITE_SIZE as read")
-json.dump({"env_random": {"fuse": F, "lanes": 65536, "kernel": "env_jump_kernel<2>", "launches": nf,
-                          "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "bytes_per_launch": (2 * f + w) * 1024,
-                          "source": f"profiles/{TAG}_env_random_fuse{F}_pmc_summary.json: " + src},
-           "mpc": {"fuse": 1, "lanes": 65536, "kernel": km, "FETCH_SIZE_KB": fm, "WRITE_SIZE_KB": wm,
-                   "bytes_per_launch": (2 * fm + wm) * 1024,
-                   "source": f"profiles/{TAG}_mpc_pmc_summary.json: " + src}},
-          open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
-ks = d["kernel_stats"]["void env_jump_kernel<2>"]
-b = json.loads(open(os.path.join(G, "bench_final.json")).read().strip().split("\n")[-1])
-print("rocprof avg_ns", ks["avg_ns"], "calls", ks["calls"], "| bench avg_launch_us", b["roofline"]["avg_launch_us"],
-      "value", b["value"], "traffic", b["roofline"]["traffic"])
+
+def stats(path):
+    out = {}
+    for f in glob.glob(path + "/**/*kernel_stats.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[r["Name"].split("(")[0].replace("void ", "")] = dict(
+                calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"]))
+    return out
+
+
+def stage(O):
+    s = {"stats_env": stats(O + "/stats_env"), "stats_mpc": stats(O + "/stats_mpc"),
+         "stats_env_mpc": stats(O + "/stats_env_mpc")}
+    for k in ("fetch_env", "write_env", "fetch_mpc", "write_mpc", "sq_env_g1", "sq_env_g2", "sq_env_g3"):
+        s[k] = counters(O + "/" + k)
+    json.dump(s, open(O + "/summary.json", "w"), indent=1)
+    print(json.dumps({k: list(v)[:4] for k, v in s.items()}, indent=1)[:2000])
+
+
+def collect():
+    G, P = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles")
+    s = json.load(open(os.path.join(G, "summary.json")))
+    for src, dst in (("bench_default.json", "bench_default.json"), ("bench_driver_args.json", "bench_driver_args.json"),
+                     ("bench_mpc.json", "bench_mpc.json"), ("bench_env_mpc.json", "bench_env_mpc.json"),
+                     ("sweeps.txt", "sweeps.txt"), ("role_stamps.txt", "role_stamps.txt")):
+        if os.path.exists(os.path.join(G, src)):
+            shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{dst}"))
+    for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_mpc", "mpc_kernel_stats.csv"),
+                      ("stats_env_mpc", "env_mpc_kernel_stats.csv")):
+        fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True))
+        if fs:
+            shutil.copy(fs[-1], os.path.join(P, f"{TAG}_{dst}"))
+    json.dump({k: s[k] for k in ("fetch_env", "write_env", "fetch_mpc", "write_mpc")},
+              open(os.path.join(P, f"{TAG}_hbm_pmc_summary.json"), "w"), indent=1)
+    # ---- HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read) ----
+    src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_r02_final.sh), "
+           "per-launch averages in KB; FETCH_SIZE doubled (gfx950 reports half of a coalesced read, "
+           "MI355X_MICROARCH.md 'HBM'; our 4-8 B/lane reads are outside the calibrated 16 B/lane case, "
+           "so the read side is an upper estimate), WRITE_SIZE as read")
+    traffic = {}
+    for wl, kern, f, w, fuse in (("env_random", ENV_KERNEL, "fetch_env", "write_env", FUSE),
+                                 ("mpc", MPC_KERNEL, "fetch_mpc", "write_mpc", 1)):
+        fk = [k for k in s[f] if k.startswith(kern.split("<")[0]) and (kern in k or wl == "mpc")]
+        if not fk:
+            continue
+        k = fk[0]
+        fe, nf = s[f][k]["FETCH_SIZE"]
+        wr, _ = s[w][k]["WRITE_SIZE"]
+        traffic[wl] = {"fuse": fuse, "lanes": LANES, "kernel": kern.replace(", 1>", ">").replace(", ", ","),
+                       "profiled_kernel": k, "launches": nf, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr,
+                       "bytes_per_launch": (2 * fe + wr) * 1024,
+                       "source": f"profiles/{TAG}_hbm_pmc_summary.json: " + src}
+    json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+    # ---- SQ counters of the env kernel and what binds it ----
+    c = {}
+    for g in ("sq_env_g1", "sq_env_g2", "sq_env_g3"):
+        for k, v in s[g].items():
+            if k.startswith(ENV_KERNEL):
+                c.update({n: m for n, (m, _) in v.items()})
+    ks = [v for k, v in s["stats_env"].items() if k.startswith(ENV_KERNEL)]
+    if c and ks:
+        waves = c["SQ_WAVES"]
+        n_simd = 1024
+        dur_s = ks[0]["avg_ns"] * 1e-9
+        valu_per_simd = c["SQ_INSTS_VALU"] / n_simd
+        derived = {
+            "waves_per_launch": waves,
+            "valu_insts_per_lane_group_per_decision": c["SQ_INSTS_VALU"] / (LANES / 64) / FUSE,
+            "salu_insts_per_lane_group_per_decision": c["SQ_INSTS_SALU"] / (LANES / 64) / FUSE,
+            "lds_insts_per_lane_group_per_decision": c["SQ_INSTS_LDS"] / (LANES / 64) / FUSE,
+            "wave_cycles_per_decision": c["SQ_WAVE_CYCLES"] * 4 / waves / FUSE,
+            "wait_fraction": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+            "active_fraction": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+            "avg_active_lanes_per_valu_inst": c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]}
+        binding = {"resource": "valu_issue",
+                   "frac": valu_per_simd * 4.0 / (dur_s * 2.4e9),
+                   "active_lanes": derived["avg_active_lanes_per_valu_inst"],
+                   "valu_insts_per_simd_per_launch": valu_per_simd, "kernel_us": dur_s * 1e6,
+                   "definition": "vector instructions per SIMD per launch x 4 cycles / (kernel time x 2.4 GHz); "
+                                 "active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
+        json.dump({"kernel": ENV_KERNEL, "lanes": LANES, "fuse": FUSE,
+                   "config": f"{LANES} lanes, fuse {FUSE}, two waves (download role, player role) per 64 lanes",
+                   "per_launch_average": c, "derived": derived, "binding": binding},
+                  open(os.path.join(P, f"{TAG}_env_split_sq_counters.json"), "w"), indent=1)
+        print("binding", binding)
+    print("traffic", {k: v["bytes_per_launch"] for k, v in traffic.items()})
+    print("kernel stats", {k: v for k, v in s["stats_env"].items() if "env_" in k})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", default="")
+    a = ap.parse_args()
+    stage(a.stage) if a.stage else collect()
