@@ -52,7 +52,7 @@ flat, J = ctl.last_flat.cpu().numpy(), ctl.last_J.cpu().numpy()
 hn_g, hs_g = ci.hist_n.cpu().numpy(), ci.hist_sum_inv.cpu().numpy()
 
 cfg = O.mpc_cfg(B, H, V, L, mb, 1.0, 4.3, 0.0)
-cores = bench.host_cores()
+cores, _ = bench.host_cores()
 
 
 def run(idx):

@@ -2,7 +2,7 @@
 """One-off soak on the GPU box: a fused random-policy rollout of N lanes x 48 decisions on the
 MI355X against the C oracle on the host cores, comparing EVERY lane's previous_bandwidths
 (float64, bit-exact), final clocks and buffer (bit-exact) and episode QoE (1e-10).
-usage: python tools/soak_parity.py [n_lanes] [mixed]"""
+usage: python tools/soak_parity.py [n_lanes] [mixed|uniform] [impl]"""
 import json
 import os
 import sys
@@ -20,11 +20,12 @@ from oracle import oracle as O  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1048576
 mixed = len(sys.argv) > 2 and sys.argv[2] == "mixed"
+impl = sys.argv[3] if len(sys.argv) > 3 else "auto"
 V, seed = bench.V, 20260404
 traces = bench.synth_traces(mixed)
 tid, off = bench.lane_assignment(0, N, traces)
 env = A.BatchedABREnv(A.MPD(V, bench.L, bench.MAX_BUFFER, bench.START_UP, A.Chunk(bench.LADDER)),
-                      A.QOEMetric(*bench.WEIGHTS), A.NetworkInfo(bench.INTERVAL, traces), N)
+                      A.QOEMetric(*bench.WEIGHTS), A.NetworkInfo(bench.INTERVAL, traces), N, impl=impl)
 env.reset(torch.from_numpy(tid), torch.from_numpy(off))
 t0 = time.perf_counter()
 out = env.step_random(V, seed, out=dict(obs=None, reward=None, done=None,
@@ -37,7 +38,7 @@ f = {k: v.cpu().numpy() for k, v in env.observe_f64().items()}
 qoe = env.episode_qoe().cpu().numpy()
 
 cfg = O.env_cfg(bench.LADDER, bench.L, V, bench.MAX_BUFFER, bench.START_UP, bench.INTERVAL, bench.WEIGHTS, 1.0)
-cores = bench.host_cores()
+cores, _ = bench.host_cores()
 chunks = np.array_split(np.arange(N), cores * 4)
 
 def run(idx):
@@ -53,7 +54,7 @@ with ThreadPoolExecutor(cores) as ex:
             bad += int((f[k][idx] != fin[k]).sum())
         bad += int((~np.isclose(qoe[idx], fin["qoe"], rtol=1e-10, atol=0)).sum())
 t_cpu = time.perf_counter() - t0
-res = dict(lanes=N, decisions=N * V, mixed_traces=mixed, mismatches=bad, gpu_seconds=round(t_gpu, 4),
+res = dict(lanes=N, impl=impl, decisions=N * V, mixed_traces=mixed, mismatches=bad, gpu_seconds=round(t_gpu, 4),
            oracle_seconds=round(t_cpu, 2), oracle_threads=cores,
            compared="previous_bandwidths float64 [V,N] ==, final global/rebuffer/start_up/play time "
                     "and buffer_level ==, episode QoE rtol 1e-10")
