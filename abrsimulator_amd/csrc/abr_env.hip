@@ -857,6 +857,9 @@ __device__ __forceinline__ void split_role_download(
                         abrx::cursor_init(cur, offset0);
                     } else d_alive = false;
                 }
+                // a call site at or past max_ticks never happens (the player times the lane out,
+                // and avail_tick is INT_MAX past the table): nothing to download speculatively
+                if (d_k >= tb.max_ticks) d_alive = false;
             }
         }
         m.flags[cb][l] = flags;

@@ -313,7 +313,7 @@ ABR_HD StepStart lanej_begin_select(Cursor &s, const Tables &t, const StepLoads 
         // more than kCatch intervals behind (a long buffer_full wait): walk, then reload
         s.j += kCatch; s.tpos = trace_wrap(s.tpos + kCatch, s.tlen);
         int32_t e = t.interval_tick[s.j + 1];
-        while (k >= e) {
+        while (k >= e && e != 0x7fffffff) {       // the table ends in INT_MAX sentinels
             s.j++;
             s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
             e = t.interval_tick[s.j + 1];

@@ -485,3 +485,54 @@ def test_hip_graph_capture_of_step():
         g.replay()
         assert torch.equal(env.obs, ref[s][0]) and torch.equal(env.reward, ref[s][1])
         assert torch.equal(env.done, ref[s][2])
+
+
+def test_timeouts_are_identical_on_every_implementation():
+    """Lanes that run into max_ticks (ABR_DONE_TIMEOUT; the reference would simply keep looping):
+    a starved network and a tick budget barely above the live-stream minimum, so that lanes time
+    out inside a download, right after one, and while waiting.  The three implementations must
+    agree on every output and on the final float64 state, step by step and fused."""
+    rng = np.random.default_rng(71)
+    V, N, L = 10, 512, 4.0
+    traces = [rng.uniform(0.02, 2.5, 800).astype(np.float32).astype(np.float64) for _ in range(6)]
+    meta = dict(ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=L, video_length=V, max_buffer=20.0,
+                start_up_length=8.0, interval=1.0, weights=[4.3, 1, 1, 0.1], speed=1.0)
+    trace_id = rng.integers(0, 6, N).astype(np.int32)
+    offset = rng.integers(0, 800, N).astype(np.int32)
+    actions = rng.integers(0, 6, (N, V)).astype(np.int32)
+    mt = (V + 1) * 400 + 700
+    ref = None
+    for impl in IMPLS:
+        env = make_env(meta, traces, N, impl=impl, max_ticks=mt)
+        env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+        acts = torch.from_numpy(actions).cuda()
+        rec = []
+        for s in range(V):
+            o, r, d = env.step(acts[:, s].contiguous())
+            rec.append((o.clone(), r.clone(), d.clone()))
+        f = {k: v.clone() for k, v in env.observe_f64().items()}
+        d_last = rec[-1][2].cpu().numpy()
+        assert ((d_last & 2) != 0).sum() > 20 and (d_last == 1).sum() > 20, np.bincount(d_last)
+        if ref is None:
+            ref = (rec, f)
+            continue
+        for s in range(V):
+            assert torch.equal(rec[s][2], ref[0][s][2]), (impl, s, "done")
+            # the event-driven kernels agree on everything; the tick-by-tick kernel stops a timed-out
+            # lane at a block boundary, so its frozen counters differ (DESIGN.md: not a parity claim)
+            ok = (rec[s][2] & 2) == 0 if impl == "tick" else torch.ones_like(rec[s][2], dtype=torch.bool)
+            assert torch.equal(rec[s][0][:, ok], ref[0][s][0][:, ok]), (impl, s, "obs")
+            assert torch.equal(rec[s][1][ok], ref[0][s][1][ok]), (impl, s, "reward")
+        ok = (rec[-1][2] & 2) == 0 if impl == "tick" else torch.ones_like(rec[-1][2], dtype=torch.bool)
+        for k in f:
+            if k not in ("average_latency",):
+                assert torch.equal(f[k][ok], ref[1][k][ok]), (impl, k)
+    # fused random rollout: split == jump on a workload where most lanes time out
+    outs = []
+    for impl in ("split", "jump"):
+        env = make_env(meta, traces, N, impl=impl, max_ticks=mt, auto_reset=True)
+        env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+        outs.append(env.step_random(2 * V, 5))
+    for k in ("obs", "reward", "done", "actions"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert int(((outs[0]["done"][-1] & 2) != 0).sum()) > 20
