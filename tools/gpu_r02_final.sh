@@ -24,6 +24,7 @@ python bench.py --mixed-traces --steps 960 --warmup 96 --no-cpu-baseline --no-se
 for I in jump tick; do python bench.py --impl $I --steps 480 --warmup 96 --no-cpu-baseline --no-secondary 2>/dev/null | line other_impl; done
 python bench.py --impl jump --lanes-per-gpu 1048576 --steps 480 --warmup 96 --no-cpu-baseline --no-secondary 2>/dev/null | line other_impl
 echo "sweeps done"
+make -C abrsimulator_amd/csrc -s libabr_hip_stamps.so      # diagnostic build (not built by __graft_entry__.build)
 ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 > $O/role_stamps.txt 2>&1 || true
 tail -3 $O/role_stamps.txt
 cd /tmp && export TMPDIR=/tmp
