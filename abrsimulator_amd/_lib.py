@@ -51,7 +51,8 @@ class MpcConfig(C.Structure):
 
 class MpcOptions(C.Structure):
     _fields_ = [("predictor", C.c_int32), ("utility", C.c_int32), ("hist_dev", C.c_void_p),
-                ("hist_stride", C.c_int64), ("hist_len_dev", C.c_void_p)]
+                ("hist_stride", C.c_int64), ("hist_len_dev", C.c_void_p),
+                ("scratch_dev", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
 class StateView(C.Structure):
@@ -82,6 +83,7 @@ SYMBOLS = [
     ("abr_env_get_state", C.c_int, [_P, C.POINTER(StateView)]),
     ("abr_mpc_select", C.c_int, [C.POINTER(MpcConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  C.c_int64, _P]),
+    ("abr_mpc_scratch_bytes", C.c_int, [C.POINTER(MpcConfig), C.c_int64, C.POINTER(C.c_size_t)]),
     ("abr_mpc_select_opt", C.c_int, [C.POINTER(MpcConfig), C.POINTER(MpcOptions), _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, C.c_int64, _P]),
     ("abr_env_step_mpc", C.c_int, [_P, C.POINTER(MpcConfig), _P, _P, C.c_int32, _P, _P, _P, _P, _P]),

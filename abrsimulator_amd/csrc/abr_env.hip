@@ -141,6 +141,7 @@ struct abr_env {
                 // 2 = role-split event-driven kernels, 0 = event-driven, one thread per lane,
                 // 1 = tick-by-tick kernels (cross-check)
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
+    void *mpc_scratch;              // predictor scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds / _speed_schedule: latched by the next full reset
     int32_t pending_speed_rows;
     bool speeds_dirty;
@@ -1101,11 +1102,15 @@ __global__ void observe_f64_kernel(EnvParams p, double *__restrict__ out) {
 // host side of the env ABI
 // ---------------------------------------------------------------------------
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// scratch of the fused MPC rollout's predictor kernel, sized for the longest horizon
+static size_t mpc_scratch_bytes_max(size_t n_lanes) {
+    return n_lanes * ((size_t)ABR_MAX_HORIZON * sizeof(double) + 2 * sizeof(int32_t));
+}
 
 struct Layout {
     size_t G, GP, interval_tick, avail_tick;        // table offsets
     size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms, ep_actions;
-    size_t mpc_action;
+    size_t mpc_action, mpc_scratch;
     size_t total;
     int32_t max_ticks, n_intervals;
 };
@@ -1175,6 +1180,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->ep_terms = o; o = align_up(o + sizeof(double) * 4 * N, A);
     L->ep_actions = o; o = align_up(o + V * N, A);
     L->mpc_action = o; o = align_up(o + sizeof(int32_t) * N, A);
+    L->mpc_scratch = o; o = align_up(o + mpc_scratch_bytes_max(N), A);
     L->total = o;
     return ABR_OK;
 }
@@ -1256,6 +1262,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     p.ep_qoe_terms = (double *)(w + L.ep_terms);
     p.ep_actions = (uint8_t *)(w + L.ep_actions);
     e->mpc_action = (int32_t *)(w + L.mpc_action);
+    e->mpc_scratch = (void *)(w + L.mpc_scratch);
 
     hipStream_t st = (hipStream_t)stream;
     hipError_t he;
@@ -1454,6 +1461,11 @@ struct MpcParams {
     const double *hist;        // predictor 1: previous_bandwidths, entry t of lane i at hist[t * hist_stride + i]
     int64_t hist_stride;
     const int32_t *hist_len;   // predictor 1: len(previous_bandwidths) per lane
+    // phase 1 run ahead of the search kernel by mpc_predict_kernel (caller-provided scratch), or null
+    const double *pre_pred;    // [H][n_lanes]
+    const int32_t *pre_he, *pre_prev;
+    double *pre_pred_w;        // the same arrays, writable, for mpc_predict_kernel
+    int32_t *pre_he_w, *pre_prev_w;
     const uint8_t *mask;
     int32_t mask_is_done;      // mask[] holds ABR_DONE_* bits: a lane is active iff its byte is 0
     int32_t neg_to_zero;       // report "no decision" (-1: D13 / D12) as bitrate 0 in action_out
@@ -1600,6 +1612,75 @@ __device__ inline int32_t mpc_resolve_group(const MpcLds &t, int H, int32_t gfla
     return gflat * B;     // unreachable: xbest was produced by this very arithmetic
 }
 
+// Phase 1 of K3 for one lane: validates chunk / previous_bitrate, runs the throughput predictor
+// (growing the caller's history, D9, in the harmonic branch) and writes the H predictions to
+// pred[i * stride].  Returns the effective horizon (0 = no decision); prev_out = previous_bitrate
+// as the index Python would use.
+__device__ inline int mpc_predict_lane(const MpcParams &p, int64_t lane, int B, int H, double *pred,
+                                       int64_t stride, int &prev_out) {
+    double n = p.hist_n[lane], S = p.hist_s[lane];
+    int c = p.chunk[lane];
+    int he = H;
+    if (c + H > p.V) he = p.clip ? (p.V - c) : 0;  // D12
+    if (he < 0) he = 0;
+    // R[0] = previous_bitrate indexes bitrates[i] (mpc.py:132,148): Python wraps -B..-1 to
+    // the top of the ladder (the env's "no previous chunk" value -1 -> the highest rate) and
+    // raises IndexError outside [-B, B)
+    int pv = p.prev[lane];
+    const bool prev_ok = (pv >= -B) && (pv < B);
+    if (pv < 0) pv += B;
+    prev_out = prev_ok ? pv : 0;
+    if (p.predictor == 1) {
+        // method="expsmoothing" (mpc.py:72-79): SimpleExpSmoothing(data).fit(0.5), then the
+        // H out-of-sample forecasts -- all equal to the last smoothed level.  statsmodels is
+        // not available to pin this against (PARITY UNPINNED); the rule implemented is the
+        // documented one: smoothing level 0.5, initial level = the least-squares optimum of
+        // the one-step-ahead errors (what fit()'s default `estimated` initialisation
+        // approximates numerically), in closed form.  With l(t-1) = a + b*l0 the level before
+        // observation y(t):  l0 = sum b (y - a) / sum b^2.  The history is NOT grown (the
+        // reference's branch returns before the append of mpc.py:92).
+        const int32_t hl = p.hist_len ? p.hist_len[lane] : 0;
+        if (hl <= 0 || c < 0 || !prev_ok) return 0;
+        double a = 0.0, b = 1.0, num = 0.0, den = 0.0;
+        for (int32_t tt = 0; tt < hl; tt++) {
+            const double y = p.hist[(int64_t)tt * p.hist_stride + lane];
+            num = num + b * (y - a);
+            den = den + b * b;
+            a = 0.5 * y + 0.5 * a;
+            b = 0.5 * b;
+        }
+        const double level = a + b * (num / den);
+        if (!(level > 0.0)) return 0;
+        for (int i = 0; i < H; i++) pred[(int64_t)i * stride] = level;
+        return he;
+    }
+    if (!(n > 0.0) || !(S > 0.0) || c < 0 || !prev_ok) {
+        // D13: empty / zero throughput history -- the reference raises ZeroDivisionError
+        // (mpc.py:88,90); likewise an out-of-range previous_bitrate (IndexError).  Defined
+        // here as "no decision": history untouched, action -1.
+        return 0;
+    }
+    for (int i = 0; i < H; i++) {
+        double tp = n / S;            // history_size / sum_inverse  (:90)
+        pred[(int64_t)i * stride] = tp;
+        S = S + 1.0 / tp;             // throughput_values.append(tp): next pass sums it last
+        n = n + 1.0;
+    }
+    p.hist_n[lane] = n; p.hist_s[lane] = S;    // D9: the caller's list has grown by H
+    return he;
+}
+
+// Phase 1 for every lane ahead of the search kernel (one thread per lane): ten dependent IEEE
+// divisions that would otherwise run on 1 of a lane's 36 threads while the other 35 wait.
+__global__ void mpc_predict_kernel(MpcParams p) {
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= p.n_lanes) return;
+    if (p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0))) return;
+    int pv;
+    const int he = mpc_predict_lane(p, lane, p.B, p.H, p.pre_pred_w + lane, p.n_lanes, pv);
+    p.pre_he_w[lane] = he; p.pre_prev_w[lane] = pv;
+}
+
 constexpr int kMpcLanesPerBlock = 16;
 
 // Threads of a block: (lane-in-block, prefix) pairs.  D = number of leading
@@ -1626,59 +1707,19 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
                        !(p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0)));
     double *my = tab + (li < LPB ? li : 0) * per_lane;
 
-    // ---- phase 1: harmonic predictor, one thread per lane (mpc.py:81-93) ----
+    // ---- phase 1: the predictor, one thread per lane (mpc.py:81-93 / :72-79) -- or its result, when
+    //      mpc_predict_kernel already ran it for every lane (p.pre_pred != nullptr) ----
     if (valid && pre == 0) {
-        double n = p.hist_n[lane], S = p.hist_s[lane];
-        int c = p.chunk[lane];
-        int he = H;
-        if (c + H > p.V) he = p.clip ? (p.V - c) : 0;  // D12
-        if (he < 0) he = 0;
-        // R[0] = previous_bitrate indexes bitrates[i] (mpc.py:132,148): Python wraps -B..-1 to
-        // the top of the ladder (the env's "no previous chunk" value -1 -> the highest rate) and
-        // raises IndexError outside [-B, B)
-        int pv = p.prev[lane];
-        const bool prev_ok = (pv >= -B) && (pv < B);
-        if (pv < 0) pv += B;
-        prev_s[li] = prev_ok ? pv : 0;
-        if (p.predictor == 1) {
-            // method="expsmoothing" (mpc.py:72-79): SimpleExpSmoothing(data).fit(0.5), then the
-            // H out-of-sample forecasts -- all equal to the last smoothed level.  statsmodels is
-            // not available to pin this against (PARITY UNPINNED); the rule implemented is the
-            // documented one: smoothing level 0.5, initial level = the least-squares optimum of
-            // the one-step-ahead errors (what fit()'s default `estimated` initialisation
-            // approximates numerically), in closed form.  With l(t-1) = a + b*l0 the level before
-            // observation y(t):  l0 = sum b (y - a) / sum b^2.  The history is NOT grown (the
-            // reference's branch returns before the append of mpc.py:92).
-            const int32_t hl = p.hist_len ? p.hist_len[lane] : 0;
-            if (hl <= 0 || c < 0 || !prev_ok) he = 0;
-            else {
-                double a = 0.0, b = 1.0, num = 0.0, den = 0.0;
-                for (int32_t tt = 0; tt < hl; tt++) {
-                    const double y = p.hist[(int64_t)tt * p.hist_stride + lane];
-                    num = num + b * (y - a);
-                    den = den + b * b;
-                    a = 0.5 * y + 0.5 * a;
-                    b = 0.5 * b;
-                }
-                const double level = a + b * (num / den);
-                if (!(level > 0.0)) he = 0;
-                else for (int i = 0; i < H; i++) my[3 * HB + i] = level;
-            }
-        } else if (!(n > 0.0) || !(S > 0.0) || c < 0 || !prev_ok) {
-            // D13: empty / zero throughput history -- the reference raises ZeroDivisionError
-            // (mpc.py:88,90); likewise an out-of-range previous_bitrate (IndexError).  Defined
-            // here as "no decision": history untouched, action -1.
-            he = 0;
+        if (p.pre_pred) {
+            const int he = p.pre_he[lane];
+            for (int i = 0; i < H; i++) my[3 * HB + i] = p.pre_pred[(int64_t)i * p.n_lanes + lane];
+            prev_s[li] = p.pre_prev[lane];
+            heff_s[li] = he;
         } else {
-            for (int i = 0; i < H; i++) {
-                double tp = n / S;            // history_size / sum_inverse  (:90)
-                my[3 * HB + i] = tp;
-                S = S + 1.0 / tp;             // throughput_values.append(tp): next pass sums it last
-                n = n + 1.0;
-            }
-            p.hist_n[lane] = n; p.hist_s[lane] = S;    // D9: the caller's list has grown by H
+            int pv;
+            heff_s[li] = mpc_predict_lane(p, lane, B, H, my + 3 * HB, 1, pv);
+            prev_s[li] = pv;
         }
-        heff_s[li] = he;
     }
     __syncthreads();
     // ---- phase 2: the per-(level, rate) tables, 60 divisions per lane spread over T threads ----
@@ -1767,14 +1808,28 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     //      ascending flat index), then the winning leaf inside the winning group ----
     if (!valid && pre == 0 && li < LPB && lane < p.n_lanes && p.mask_is_done)
         p.action_out[lane] = -1;          // a finished lane of the fused rollout takes no decision
-    if (valid && pre == 0) {
-        double bx = -INFINITY; int32_t bf = 0x7fffffff; bool have = false;
-        for (int q2 = 0; q2 < T; q2++) {
-            const double x = bestJ[li * T + q2];
-            const int32_t f = bestF[li * T + q2];
-            if (f == 0x7fffffff) continue;
-            if (!have || x > bx) { bx = x; bf = f; have = true; }
+    // pairwise tree over the lane's T entries: an entry beats another if it is valid and has the
+    // larger x, or the same x and the smaller flat index (= the serial left-to-right scan with
+    // strict `>`: ascending prefix is ascending flat index)
+    {
+        int tp2 = 1;
+        while (tp2 < T) tp2 <<= 1;
+        for (int sft = tp2 >> 1; sft > 0; sft >>= 1) {
+            if (li < LPB && pre < sft && pre + sft < T) {
+                const int ia = li * T + pre, ib = ia + sft;
+                const int32_t fa = bestF[ia], fb = bestF[ib];
+                const double xa = bestJ[ia], xb = bestJ[ib];
+                const bool take = (fb != 0x7fffffff) &&
+                                  ((fa == 0x7fffffff) || (xb > xa) || (xb == xa && fb < fa));
+                if (take) { bestJ[ia] = xb; bestF[ia] = fb; }
+            }
+            __syncthreads();
         }
+    }
+    if (valid && pre == 0) {
+        const double bx = bestJ[li * T];
+        int32_t bf = bestF[li * T];
+        const bool have = bf != 0x7fffffff;
         const int he = heff_s[li];
         int32_t act = -1;
         if (have) {
@@ -1841,10 +1896,25 @@ static void fill_mpc_params(MpcParams &p, const abr_mpc_config *cfg, int64_t n_l
     p.wr = cfg->rebuffer_weight; p.ws = cfg->startup_weight; p.n_lanes = n_lanes;
     p.mask = nullptr; p.mask_is_done = 0; p.neg_to_zero = 0;
     p.predictor = 0; p.utility = 0; p.hist = nullptr; p.hist_stride = 0; p.hist_len = nullptr;
+    p.pre_pred = nullptr; p.pre_he = nullptr; p.pre_prev = nullptr;
+    p.pre_pred_w = nullptr; p.pre_he_w = nullptr; p.pre_prev_w = nullptr;
     p.flat_out = nullptr; p.J_out = nullptr;
 }
 
-static int launch_mpc_select(const MpcParams &p, hipStream_t st) {
+static size_t mpc_scratch_bytes(int H, int64_t n_lanes) {
+    return (size_t)n_lanes * ((size_t)H * sizeof(double) + 2 * sizeof(int32_t));
+}
+
+// scratch != nullptr: run phase 1 as its own kernel first
+static int launch_mpc_select(MpcParams p, hipStream_t st, void *scratch = nullptr) {
+    if (scratch) {
+        p.pre_pred_w = (double *)scratch;
+        p.pre_he_w = (int32_t *)(p.pre_pred_w + (size_t)p.H * p.n_lanes);
+        p.pre_prev_w = p.pre_he_w + p.n_lanes;
+        p.pre_pred = nullptr;                      // the predictor kernel itself must not read "pre"
+        hipLaunchKernelGGL(mpc_predict_kernel, dim3((unsigned)((p.n_lanes + 255) / 256)), dim3(256), 0, st, p);
+        p.pre_pred = p.pre_pred_w; p.pre_he = p.pre_he_w; p.pre_prev = p.pre_prev_w;
+    }
     const int D = (p.H >= 3) ? 2 : 1;
     int T = p.B; if (D == 2) T *= p.B;
     switch (p.H) {
@@ -1893,6 +1963,19 @@ static int apply_mpc_options(MpcParams &p, const abr_mpc_options *opt) {
         return fail(ABR_E_INVALID, "exponential smoothing needs the history itself: hist_dev, hist_stride, hist_len_dev");
     p.predictor = opt->predictor; p.utility = opt->utility;
     p.hist = opt->hist_dev; p.hist_stride = opt->hist_stride; p.hist_len = opt->hist_len_dev;
+    if (opt->scratch_dev && opt->scratch_bytes < mpc_scratch_bytes(p.H, p.n_lanes))
+        return fail(ABR_E_WORKSPACE, "MPC scratch has %zu bytes, need %zu", (size_t)opt->scratch_bytes,
+                    mpc_scratch_bytes(p.H, p.n_lanes));
+    if (opt->scratch_dev && ((uintptr_t)opt->scratch_dev & 7))
+        return fail(ABR_E_WORKSPACE, "MPC scratch must be 8-byte aligned");
+    return ABR_OK;
+}
+
+extern "C" int abr_mpc_scratch_bytes(const abr_mpc_config *cfg, int64_t n_lanes, size_t *bytes_out) {
+    int rc = validate_mpc(cfg);
+    if (rc) return rc;
+    if (n_lanes < 1 || !bytes_out) return fail(ABR_E_INVALID, "n_lanes must be >= 1 and bytes_out non-NULL");
+    *bytes_out = mpc_scratch_bytes(cfg->horizon, n_lanes);
     return ABR_OK;
 }
 
@@ -1917,7 +2000,7 @@ extern "C" int abr_mpc_select_opt(const abr_mpc_config *cfg, const abr_mpc_optio
     p.hist_n = hist_n_dev; p.hist_s = hist_sum_inv_dev; p.br = br_table_dev; p.sz = sz_table_dev;
     p.mask = lane_mask_dev; p.action_out = action_out_dev; p.flat_out = best_flat_out_dev;
     p.J_out = best_J_out_dev;
-    return launch_mpc_select(p, (hipStream_t)stream);
+    return launch_mpc_select(p, (hipStream_t)stream, opt ? opt->scratch_dev : nullptr);
 }
 
 // The composition the reference leaves unwired (D5/D6): for n_steps decisions,
@@ -1951,7 +2034,7 @@ extern "C" int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg,
     for (int32_t s = 0; s < n_steps; s++) {
         int32_t *act = actions_out_dev ? actions_out_dev + (int64_t)s * N : env->mpc_action;
         p.action_out = act;
-        rc = launch_mpc_select(p, st);
+        rc = launch_mpc_select(p, st, env->mpc_scratch);
         if (rc) return rc;
         float *obs = obs_out_dev ? obs_out_dev + (int64_t)s * ABR_OBS_DIM * N : nullptr;
         float *rew = reward_out_dev ? reward_out_dev + (int64_t)s * N : nullptr;

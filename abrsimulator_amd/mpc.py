@@ -3,6 +3,7 @@ for many players at once.  next_bitrate() is one launch of the K3 kernel
 (csrc/abr_env.hip: mpc_select_kernel) through the C ABI.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -44,6 +45,9 @@ class BatchedMPCController:
         if method not in self.METHODS or utility not in self.UTILITIES:
             raise ValueError("method is 'harmonic' or 'expsmoothing'; utility is 'identity' or 'log'")
         self.method, self.utility = method, utility
+        # run the predictor as its own kernel (False: everything in one kernel; same results)
+        self.use_scratch = os.environ.get("ABR_MPC_SINGLE_KERNEL") != "1"
+        self._scratch = None
         self.player = None
         self._tables_for = None
         if player is not None:
@@ -103,21 +107,26 @@ class BatchedMPCController:
                       (ci.hist_sum_inv, torch.float64)):
             if t.dtype != dt or t.device.type != "cuda":
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
-        opt = None
-        if self.method != "harmonic" or self.utility != "identity":
-            opt = _lib.MpcOptions()
-            opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
-            if self.method == "expsmoothing":
-                hist, hlen = ci.previous_bandwidths, ci.history_length
-                if hist.dtype != torch.float64 or hist.dim() != 2 or hist.shape[1] != N or hist.stride(1) != 1:
-                    raise TypeError("previous_bandwidths must be float64 [T, N] with unit lane stride")
-                if hlen.dtype != torch.int32 or int(hlen.max()) > hist.shape[0]:
-                    raise TypeError("history_length must be int32 [N], at most T")
-                opt.hist_dev, opt.hist_stride = hist.data_ptr(), hist.stride(0)
-                opt.hist_len_dev = hlen.data_ptr()
+        opt = _lib.MpcOptions()
+        opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
+        if self.use_scratch:
+            # scratch for the predictor pre-kernel (include/abr_env.h: abr_mpc_options.scratch_dev)
+            need = C.c_size_t()
+            _lib.check(self.lib.abr_mpc_scratch_bytes(C.byref(cfg), N, C.byref(need)))
+            if self._scratch is None or self._scratch.numel() < need.value:
+                self._scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            opt.scratch_dev, opt.scratch_bytes = self._scratch.data_ptr(), self._scratch.numel()
+        if self.method == "expsmoothing":
+            hist, hlen = ci.previous_bandwidths, ci.history_length
+            if hist.dtype != torch.float64 or hist.dim() != 2 or hist.shape[1] != N or hist.stride(1) != 1:
+                raise TypeError("previous_bandwidths must be float64 [T, N] with unit lane stride")
+            if hlen.dtype != torch.int32 or int(hlen.max()) > hist.shape[0]:
+                raise TypeError("history_length must be int32 [N], at most T")
+            opt.hist_dev, opt.hist_stride = hist.data_ptr(), hist.stride(0)
+            opt.hist_len_dev = hlen.data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.abr_mpc_select_opt(
-                C.byref(cfg), C.byref(opt) if opt is not None else None,
+                C.byref(cfg), C.byref(opt),
                 _lib.ptr(ci.chunk_number), _lib.ptr(ci.previous_bitrate),
                 _lib.ptr(ci.buffer_level), _lib.ptr(ci.hist_n), _lib.ptr(ci.hist_sum_inv),
                 _lib.ptr(br), _lib.ptr(sz), _lib.ptr(mask), _lib.ptr(action), _lib.ptr(flat),

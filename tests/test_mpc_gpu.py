@@ -213,3 +213,37 @@ def test_empty_history_is_a_defined_no_decision():
     assert a[0] == -1 and a[2] == -1 and a[1] >= 0
     assert ci.hist_n.cpu().numpy().tolist() == [0.0, 9.0, 3.0]
     assert np.isnan(ctl.last_J.cpu().numpy()[[0, 2]]).all() and int(ctl.last_flat[0]) == -1
+
+
+def test_predictor_pre_kernel_and_single_kernel_agree(oracle):
+    """abr_mpc_options.scratch_dev: the predictor as a kernel of its own == everything in one
+    kernel == the oracle, incl. masked lanes, clipped horizons and "no decision" lanes."""
+    B, H, V, L, mb, N = 6, 5, 30, 4.0, 20.0, 3000
+    rng = np.random.default_rng(88)
+    br = np.sort(rng.uniform(0.2, 6.0, B))[None, :] * rng.uniform(0.8, 1.2, (V, B))
+    sz = br * L * rng.uniform(0.7, 1.3, (V, B))
+    chunk = rng.integers(0, V, N).astype(np.int32)                 # some within H of the end: clipped
+    prev = rng.integers(-1, B, N).astype(np.int32)
+    buf = rng.uniform(0, mb, N)
+    hn = rng.integers(0, 20, N).astype(np.float64)                 # some empty histories (D13)
+    hs = np.where(hn > 0, hn / rng.uniform(0.3, 5.0, N), 0.0)
+    mask = (rng.random(N) < 0.9).astype(np.uint8)
+    res = []
+    for scratch in (True, False):
+        ctl, ci = _controller(br, sz, L, mb, 4.3, 1.0, 0.0, H, chunk, prev, buf, hn, hs, clip=True)
+        ci.mask = torch.from_numpy(mask).cuda()
+        ctl.use_scratch = scratch
+        a = ctl.next_bitrate(want_details=True)
+        res.append((a.cpu().numpy(), ctl.last_flat.cpu().numpy(), ctl.last_J.cpu().numpy(),
+                    ci.hist_n.cpu().numpy(), ci.hist_sum_inv.cpu().numpy()))
+    m = mask.astype(bool)
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x[m], y[m], equal_nan=True)
+    assert np.array_equal(res[0][3][~m], hn[~m])                    # masked lanes untouched
+    full = m & (chunk + H <= V) & (hn > 0)
+    cfg = oracle.mpc_cfg(B, H, V, L, mb, 1.0, 4.3, 0.0)
+    hn_o, hs_o = hn[full].copy(), hs[full].copy()
+    act, flat, Jm, _ = oracle.mpc_select(cfg, br, sz, chunk[full], prev[full], buf[full], hn_o, hs_o)
+    assert np.array_equal(res[0][0][full], act) and np.array_equal(res[0][2][full], Jm)
+    assert np.array_equal(res[0][1][full].astype(np.int64), flat)
+    assert (res[0][0][m & (hn == 0)] == -1).all()
