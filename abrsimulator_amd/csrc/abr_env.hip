@@ -595,8 +595,15 @@ __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i
     obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
 }
 
+// 128 VGPRs (48 B of scratch per lane) = four waves per SIMD instead of three at 138: measured
+// +8 % at 262 144 lanes, +5 % at 1 M (same box, profiles/r02_ab_prefetch.txt); five waves
+// (96 VGPRs) was tried as well
+#ifndef ABR_JUMP_WAVES
+#define ABR_JUMP_WAVES 4
+#endif
+#define ABR_JUMP_BOUNDS __launch_bounds__(64, ABR_JUMP_WAVES)
 template <int MODE>
-__global__ __launch_bounds__(64) void env_jump_kernel(
+__global__ ABR_JUMP_BOUNDS void env_jump_kernel(
     EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
     const int32_t *__restrict__ offset_in, const uint8_t *__restrict__ lane_mask,
     float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
