@@ -359,3 +359,25 @@ def test_fused_random_rollout_with_per_chunk_ladders(oracle):
             assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), (ep, s)
             assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32)), (ep, s)
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+
+
+def test_bench_two_ranks_one_collective_per_launch():
+    """bench.py's N > 1 path end to end: two ranks (both on this box's one GPU, gloo standing in for
+    RCCL) through torch.distributed.run exactly as the driver launches it; one packed all-gather per
+    launch, in the fused mode and in the one-launch-per-decision mode (configs[3] literally)."""
+    import json
+    for fuse, steps, warm in ((48, 96, 48), (1, 24, 8)):
+        env = dict(os.environ, ABR_BENCH_ONE_DEVICE="1", ABR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+               "--fuse", str(fuse), "--total-lanes", "8192", "--no-cpu-baseline", "--min-timed-steps", "1"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total_lanes"] == 8192
+        assert line["config"]["lanes_per_gpu"] == 4096 and line["config"]["fuse"] == fuse
+        launches = (steps + warm) // fuse
+        assert line["config"]["collective"].startswith("1 all_gather_into_tensor per launch")
+        assert line["config"]["collective"].endswith(f"issued {launches}x"), line["config"]["collective"]
+        assert line["value"] > 0 and "secondary" not in line and line["cpu_baseline"] is None
