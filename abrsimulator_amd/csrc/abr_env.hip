@@ -171,6 +171,9 @@ __host__ __device__ inline uint32_t philox_action(uint64_t seed, uint64_t lane, 
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+#ifdef ABR_AB_UNIFORM_POLICY     // diagnostic build only: every lane of a wave draws the same action
+    c0 = (uint32_t)(0x9E3779B9u * (step * 31u + episode) + (uint32_t)(lane >> 6) * 0x85EBCA6Bu);
+#endif
     return (uint32_t)(((uint64_t)c0 * n_rates) >> 32);   // multiply-shift into [0, n_rates)
 }
 
