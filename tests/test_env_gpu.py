@@ -536,3 +536,32 @@ def test_timeouts_are_identical_on_every_implementation():
     for k in ("obs", "reward", "done", "actions"):
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert int(((outs[0]["done"][-1] & 2) != 0).sum()) > 20
+
+
+@pytest.mark.parametrize("V,B", [(1, 1), (1, 6), (2, 3)])
+def test_degenerate_shapes_fused_auto_reset(oracle, V, B):
+    """One-chunk videos and one-rate ladders: every step ends an episode and re-arms the lane inside
+    the kernel (the speculative download side predicts a fresh episode every time)."""
+    rng = np.random.default_rng(90 + V * 10 + B)
+    N, SEED, EPS = 200, 4242, 5
+    ladder = list(np.sort(rng.uniform(0.3, 4.0, B)))
+    traces = [rng.uniform(0.3, 6.0, 300).astype(np.float32).astype(np.float64) for _ in range(3)]
+    meta = dict(ladder=ladder, chunk_length=2.0, video_length=V, max_buffer=10.0, start_up_length=2.0,
+                interval=1.0, weights=[4.3, 1, 1, 0.1], speed=1.0)
+    tid = rng.integers(0, 3, N).astype(np.int32); off = rng.integers(0, 300, N).astype(np.int32)
+    outs = {}
+    for impl in IMPLS:
+        env = make_env(meta, traces, N, impl=impl, auto_reset=True)
+        env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+        outs[impl] = (env.step_random(EPS * V, SEED), env.episode_qoe().cpu().numpy())
+    for impl in IMPLS[1:]:
+        for k in ("obs", "reward", "done", "actions"):
+            assert torch.equal(outs[impl][0][k], outs[IMPLS[0]][0][k]), (impl, k)
+    out, qoe = outs["split"]
+    assert int(out["done"].sum()) == EPS * N
+    acts = out["actions"].cpu().numpy()
+    last = acts[(EPS - 1) * V:].T.copy()
+    assert np.array_equal(last, np.stack([philox_action(SEED, np.arange(N), s, EPS - 1, B) for s in range(V)], 1))
+    cfg = oracle.env_cfg(ladder, 2.0, V, 10.0, 2.0, 1.0, meta["weights"], 1.0)
+    _, _, fin, _ = oracle.env_batch(cfg, traces, tid, off, last)
+    assert np.allclose(qoe, fin["qoe"], rtol=1e-10)
