@@ -231,7 +231,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = "none"
-    if world > 1:
+    # ABR_BENCH_FORCE_DIST=1: a ONE-rank process group, so that the RCCL code path (communicator,
+    # all_gather_into_tensor on the side stream, events) runs on a one-GPU box too
+    force_dist = world == 1 and os.environ.get("ABR_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         backend = os.environ.get("ABR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
@@ -258,7 +266,7 @@ def main():
                   "tick": "env_advance_kernel<2>"}[impl]
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -300,7 +308,7 @@ def main():
         slabs = [make_slab(F, OBS_DIM, N, dev) for _ in range(2)]
         bufs = [dict(obs=o, reward=r, done=torch.empty(F, N, dtype=torch.uint8, device=dev), actions=None)
                 for (_, o, r, _) in slabs]
-        gather = world > 1 and not a.no_gather
+        gather = (world > 1 or force_dist) and not a.no_gather
         if gather:
             # THE one collective of the path: per launch, ONE all-gather of the packed slab
             # [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with the
@@ -368,7 +376,7 @@ def main():
         runner(n_steps, True)
         barrier()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if world > 1 or force_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
@@ -455,7 +463,7 @@ def main():
 
     if rank == 0:
         total_units = units_per_step * K
-        gathering = world > 1 and not a.no_gather and a.workload == "env_random"
+        gathering = (world > 1 or force_dist) and not a.no_gather and a.workload == "env_random"
         line = {
             "metric": metric, "value": total_units / elapsed, "unit": unit, "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
@@ -477,7 +485,7 @@ def main():
         if secondary is not None:
             line["secondary"] = secondary
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

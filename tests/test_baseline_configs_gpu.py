@@ -381,3 +381,20 @@ def test_bench_two_ranks_one_collective_per_launch():
         assert line["config"]["collective"].startswith("1 all_gather_into_tensor per launch")
         assert line["config"]["collective"].endswith(f"issued {launches}x"), line["config"]["collective"]
         assert line["value"] > 0 and "secondary" not in line and line["cpu_baseline"] is None
+
+
+def test_bench_rccl_code_path_with_one_rank():
+    """The RCCL backend itself ("nccl" on ROCm) cannot host two ranks on one GPU, but a ONE-rank
+    group can: communicator creation, all_gather_into_tensor on the side stream, events, barrier and
+    all_reduce all run through RCCL (ABR_BENCH_FORCE_DIST=1)."""
+    import json
+    env = dict(os.environ, ABR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ABR_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "96", "--warmup", "48",
+           "--lanes-per-gpu", "8192", "--no-cpu-baseline", "--no-secondary", "--min-timed-steps", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "backend nccl" in line["config"]["collective"] and line["config"]["collective"].endswith("issued 3x")
+    assert line["value"] > 0
