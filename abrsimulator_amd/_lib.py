@@ -17,7 +17,7 @@ SO_PATH = os.path.join(CSRC, "libabr_hip.so")
 if os.environ.get("ABR_HIP_LIB"):          # diagnostic builds of the same ABI (csrc/Makefile)
     SO_PATH = os.path.join(CSRC, os.environ["ABR_HIP_LIB"])
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_RATES = 16
 MAX_HORIZON = 8
 OBS_DIM = 8
@@ -78,6 +78,9 @@ SYMBOLS = [
     ("abr_env_reset", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("abr_env_step_random", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
+    ("abr_env_step_script", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    ("abr_env_get_effective_impl", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
+    ("abr_env_notify_restore", C.c_int, [_P]),
     ("abr_env_episode_qoe", C.c_int, [_P, _P, _P]),
     ("abr_env_observe_f64", C.c_int, [_P, _P, _P]),
     ("abr_env_get_state", C.c_int, [_P, C.POINTER(StateView)]),
@@ -104,7 +107,7 @@ def build(force=False):
     src = os.path.join(CSRC, "abr_env.hip")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "abr_env.h")
     deps = [src, hdr] + [os.path.join(CSRC, h) for h in
-                         ("abr_exact_jump.h", "abr_lane_jump.h", "abr_tick_tables.h")]
+                         ("abr_exact_jump.h", "abr_lane_jump.h", "abr_tick_tables.h", "abr_env_async.h")]
     stale = (not os.path.exists(SO_PATH)
              or os.path.getmtime(SO_PATH) < max(os.path.getmtime(d) for d in deps))
     if force or stale:

@@ -137,9 +137,9 @@ struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
-    int impl;   // 3 = auto (default): role-split up to kSplitMaxLanes lanes, one thread per lane above;
-                // 2 = role-split event-driven kernels, 0 = event-driven, one thread per lane,
-                // 1 = tick-by-tick kernels (cross-check)
+    int impl;   // 3 = auto (default): see effective_impl(); 4 = asynchronous role pipeline for fused rollouts
+                // (role-split for single steps), 2 = role-split event-driven kernels, 0 = event-driven,
+                // one thread per lane, 1 = tick-by-tick kernels (cross-check)
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
     void *mpc_scratch;              // predictor scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds / _speed_schedule: latched by the next full reset
@@ -147,7 +147,18 @@ struct abr_env {
     bool speeds_dirty;
     const double *pending_br_table; // abr_env_set_bitrate_table: latched the same way
     bool br_table_dirty;
+    bool armed;                     // abr_env_reset has run at least once: episodes may be in flight
 };
+
+// A handle on which no reset has run has no episode to protect: the setters take effect at once
+// (a freshly built handle that receives a checkpointed workspace must already carry them).
+static void apply_pending(abr_env *env) {
+    if (env->br_table_dirty) { env->p.br_table = env->pending_br_table; env->br_table_dirty = false; }
+    if (env->speeds_dirty) {
+        env->p.lane_speeds = env->pending_speeds; env->p.speed_rows = env->pending_speed_rows;
+        env->speeds_dirty = false;
+    }
+}
 
 // mpd.chunks[chunk].bitrates[rate]: the single ladder run() indexes (Simulator.py:82,156), or --
 // the evident intent of set_mpd's one-ladder-per-line file (Simulator.py:71-76) -- chunk's own
@@ -171,9 +182,6 @@ __host__ __device__ inline uint32_t philox_action(uint64_t seed, uint64_t lane, 
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-#ifdef ABR_AB_UNIFORM_POLICY     // diagnostic build only: every lane of a wave draws the same action
-    c0 = (uint32_t)(0x9E3779B9u * (step * 31u + episode) + (uint32_t)(lane >> 6) * 0x85EBCA6Bu);
-#endif
     return (uint32_t)(((uint64_t)c0 * n_rates) >> 32);   // multiply-shift into [0, n_rates)
 }
 
@@ -327,6 +335,7 @@ __device__ inline void copy_episode_actions(const EnvParams &p, int64_t i, int32
 // MODE 0: reset (fresh lanes run to their first call site)
 // MODE 1: step  (one externally supplied action per lane)
 // MODE 2: fused random-policy rollout of n_steps decisions per lane
+// MODE 3: fused rollout of n_steps scripted decisions per lane, actions[step][lane]
 template <int MODE>
 __global__ __launch_bounds__(64) void env_advance_kernel(
     EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
     int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < p.n_lanes;
-    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     Lane s;
     bool active = in_range;       // still has work in this launch
     bool touched = in_range;      // state must be written back
@@ -442,6 +451,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                 // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
                 int32_t a;
                 if (MODE == 1) a = actions[i];
+                else if (MODE == 3) a = actions[(int64_t)step_idx * p.n_lanes + i];
                 else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i),
                                                 (uint32_t)s.chunk_id, (uint32_t)episode_no,
                                                 (uint32_t)p.n_rates);
@@ -613,7 +623,7 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
     int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < p.n_lanes;
-    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int32_t V = p.video_length;
     const abrx::Tables tb = make_tables(p);
     LaneJ s;
@@ -667,6 +677,7 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
                 // ---- the call site: get_next_bitrate's return value (Simulator.py:155-156) ----
                 int32_t a;
                 if (MODE == 1) a = actions[i];
+                else if (MODE == 3) a = actions[o];
                 else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i),
                                                 (uint32_t)s.chunk_id, (uint32_t)episode_no,
                                                 (uint32_t)p.n_rates);
@@ -842,6 +853,7 @@ __device__ __forceinline__ void split_role_download(
             ABR_STAMP(1);
             int32_t a;
             if (MODE == 1) a = actions[i];
+            else if (MODE == 3) a = actions[(int64_t)d_step * p.n_lanes + i];
             else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
                                             (uint32_t)d_ep, (uint32_t)p.n_rates);
             if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;
@@ -1032,18 +1044,21 @@ __device__ __forceinline__ void split_role_player(
     }
 }
 
-// MODE 1: one externally supplied action per lane; MODE 2: fused random-policy rollout
+// MODE 1: one externally supplied action per lane; MODE 2: fused random-policy rollout;
+// MODE 3: fused rollout of scripted actions [n_steps][n_lanes]
 template <int MODE>
 __global__ __launch_bounds__(128) void env_split_kernel(
     EnvParams p, const int32_t *__restrict__ actions, float *__restrict__ obs_out,
     float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
     int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
     __shared__ SplitMail m;
-    const int32_t n_total = (MODE == 2) ? n_steps : 1;
+    const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     // the role is wave-uniform: each wave runs exactly one of the two loops
     if (threadIdx.x < 64) split_role_download<MODE>(p, m, actions, actions_out, n_total, seed);
     else split_role_player<MODE>(p, m, obs_out, reward_out, done_out, actions_out, n_total);
 }
+
+#include "abr_env_async.h"
 
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
@@ -1295,11 +1310,12 @@ extern "C" int abr_env_destroy(abr_env *env) {
     return ABR_OK;
 }
 
-// 2 = role-split event-driven kernels (default), 0 = event-driven, one thread per lane,
-// 1 = tick-by-tick kernels (kept as a cross-check)
+// 3 = auto (default), 4 = asynchronous role pipeline, 2 = role-split event-driven kernels,
+// 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl < 0 || impl > 3) return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split) or 3 (auto)");
+    if (impl < 0 || impl > 4)
+        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 4 (async)");
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -1316,6 +1332,7 @@ extern "C" int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev) {
     env->pending_speeds = speeds_dev;
     env->pending_speed_rows = 1;
     env->speeds_dirty = true;
+    if (!env->armed) apply_pending(env);
     return ABR_OK;
 }
 
@@ -1328,6 +1345,7 @@ extern "C" int abr_env_set_speed_schedule(abr_env *env, const double *speeds_dev
     env->pending_speeds = speeds_dev;
     env->pending_speed_rows = speeds_dev ? n_rows : 1;
     env->speeds_dirty = true;
+    if (!env->armed) apply_pending(env);
     return ABR_OK;
 }
 
@@ -1336,6 +1354,15 @@ extern "C" int abr_env_set_bitrate_table(abr_env *env, const double *br_table_de
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     env->pending_br_table = br_table_dev;
     env->br_table_dirty = true;
+    if (!env->armed) apply_pending(env);
+    return ABR_OK;
+}
+
+// the caller has copied a checkpointed workspace into this handle's workspace: episodes are in flight
+extern "C" int abr_env_notify_restore(abr_env *env) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    apply_pending(env);
+    env->armed = true;
     return ABR_OK;
 }
 
@@ -1352,9 +1379,25 @@ static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 // waves (65 536 lanes: 7.2e9 vs 6.2e9 env-steps/s); from 262 144 lanes on the plain form has
 // enough waves of its own and no barrier (1.39e10 vs 1.32e10 at 1 M).  profiles/r02_sweeps.txt
 constexpr int64_t kSplitMaxLanes = 131072;
-static inline int effective_impl(const abr_env *env) {
-    if (env->impl != 3) return env->impl;
-    return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
+// The asynchronous pipeline (abr_env_async.h) serves FUSED rollouts only (a single step has nothing to
+// run ahead of).  Measured on MI355X at 65 536 lanes, fuse 48 (profiles/r03_async_*): 714 us per launch
+// against 418 us for the role-split kernel -- its flat download loop needs 9.75 trips per decision instead
+// of 16.6, but the passes that push / restart downloads run with 21 of 64 lanes and cost more than they
+// save (3 713 vector + 2 218 scalar instructions per 64 lanes per decision against 2 526 + 757).  So
+// `auto` never picks it; it stays selectable (impl 4) and parity-tested.
+constexpr int64_t kAsyncMaxLanes = 0;
+static inline bool async_eligible(const abr_env *env) {
+    return !env->p.lane_speeds && env->p.video_length + 2 <= kAvailLds;
+}
+// fused == true: step_random / step_script (n_steps decisions per launch)
+static inline int effective_impl(const abr_env *env, bool fused = false) {
+    int impl = env->impl;
+    if (impl == 3) {
+        if (fused && env->p.n_lanes <= kAsyncMaxLanes && async_eligible(env)) return 4;
+        return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
+    }
+    if (impl == 4) return (fused && async_eligible(env)) ? 4 : 2;
+    return impl;
 }
 
 extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
@@ -1362,21 +1405,14 @@ extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
                              float *obs_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!trace_id_dev) return fail(ABR_E_INVALID, "trace_id_dev is NULL");
-    if (env->br_table_dirty) {
-        if (lane_mask_dev)
-            return fail(ABR_E_INVALID, "abr_env_set_bitrate_table takes effect at a reset of ALL lanes "
-                        "(lane_mask_dev must be NULL for the first reset after it)");
-        env->p.br_table = env->pending_br_table;
-        env->br_table_dirty = false;
-    }
-    if (env->speeds_dirty) {
-        if (lane_mask_dev)
-            return fail(ABR_E_INVALID, "abr_env_set_lane_speeds takes effect at a reset of ALL lanes "
-                        "(lane_mask_dev must be NULL for the first reset after it)");
-        env->p.lane_speeds = env->pending_speeds;
-        env->p.speed_rows = env->pending_speed_rows;
-        env->speeds_dirty = false;
-    }
+    if (env->br_table_dirty && lane_mask_dev)
+        return fail(ABR_E_INVALID, "abr_env_set_bitrate_table takes effect at a reset of ALL lanes "
+                    "(lane_mask_dev must be NULL for the first reset after it)");
+    if (env->speeds_dirty && lane_mask_dev)
+        return fail(ABR_E_INVALID, "abr_env_set_lane_speeds takes effect at a reset of ALL lanes "
+                    "(lane_mask_dev must be NULL for the first reset after it)");
+    apply_pending(env);
+    env->armed = true;
     hipLaunchKernelGGL(env->impl == 1 ? env_advance_kernel<0> : env_jump_kernel<0>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                        (hipStream_t)stream, env->p, nullptr, trace_id_dev, start_offset_dev,
                        lane_mask_dev, obs_out_dev, nullptr, nullptr, nullptr, 0, 0ull);
@@ -1401,21 +1437,57 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
     return ABR_OK;
 }
 
+// n_steps fused decisions per lane; MODE 2: built-in random policy, MODE 3: scripted actions
+// [n_steps][n_lanes].  The asynchronous pipeline takes at most kMaxFuse decisions per launch (its
+// action table lives in LDS); longer rollouts are cut into consecutive launches on the same stream.
+template <int MODE>
+static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, uint64_t seed, float *obs,
+                        float *rew, uint8_t *dn, int32_t *acts, hipStream_t st) {
+    const int impl = effective_impl(env, true);
+    const int64_t N = env->p.n_lanes;
+    if (impl == 4) {
+        for (int32_t s0 = 0; s0 < n_steps; s0 += kMaxFuse) {
+            const int32_t n = n_steps - s0 < kMaxFuse ? n_steps - s0 : kMaxFuse;
+            hipLaunchKernelGGL(env_async_kernel<MODE>, dim3((unsigned)((N + kAW - 1) / kAW)), dim3(3 * kAW), 0, st,
+                               env->p, script ? script + (int64_t)s0 * N : nullptr,
+                               obs ? obs + (int64_t)s0 * ABR_OBS_DIM * N : nullptr,
+                               rew ? rew + (int64_t)s0 * N : nullptr, dn ? dn + (int64_t)s0 * N : nullptr,
+                               acts ? acts + (int64_t)s0 * N : nullptr, n, seed);
+        }
+    } else if (impl == 2)
+        hipLaunchKernelGGL(env_split_kernel<MODE>, dim3(grid64(N)), dim3(128), 0, st, env->p, script, obs, rew,
+                           dn, acts, n_steps, seed);
+    else
+        hipLaunchKernelGGL(impl ? env_advance_kernel<MODE> : env_jump_kernel<MODE>, dim3(grid64(N)), dim3(64), 0,
+                           st, env->p, script, nullptr, nullptr, nullptr, obs, rew, dn, acts, n_steps, seed);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
 extern "C" int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed,
                                    float *obs_out_dev, float *reward_out_dev,
                                    uint8_t *done_out_dev, int32_t *actions_out_dev, void *stream) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
-    const int impl = effective_impl(env);
-    if (impl == 2)
-        hipLaunchKernelGGL(env_split_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
-                           (hipStream_t)stream, env->p, nullptr, obs_out_dev, reward_out_dev,
-                           done_out_dev, actions_out_dev, n_steps, seed);
-    else
-        hipLaunchKernelGGL(impl ? env_advance_kernel<2> : env_jump_kernel<2>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
-                           (hipStream_t)stream, env->p, nullptr, nullptr, nullptr, nullptr,
-                           obs_out_dev, reward_out_dev, done_out_dev, actions_out_dev, n_steps, seed);
-    HIP_TRY(hipGetLastError());
+    return launch_fused<2>(env, nullptr, n_steps, seed, obs_out_dev, reward_out_dev, done_out_dev,
+                           actions_out_dev, (hipStream_t)stream);
+}
+
+// The same fused rollout with the ABR controller's answers given up front: what run() does with a
+// scripted abr_controller (get_next_bitrate returns actions_dev[step][lane], Simulator.py:155).
+extern "C" int abr_env_step_script(abr_env *env, int32_t n_steps, const int32_t *actions_dev,
+                                   float *obs_out_dev, float *reward_out_dev, uint8_t *done_out_dev,
+                                   void *stream) {
+    if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    if (n_steps < 1) return fail(ABR_E_INVALID, "n_steps must be >= 1");
+    if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
+    return launch_fused<3>(env, actions_dev, n_steps, 0ull, obs_out_dev, reward_out_dev, done_out_dev,
+                           nullptr, (hipStream_t)stream);
+}
+
+extern "C" int abr_env_get_effective_impl(abr_env *env, int32_t fused, int32_t *impl_out) {
+    if (!env || !impl_out) return fail(ABR_E_INVALID, "NULL argument");
+    *impl_out = effective_impl(env, fused != 0);
     return ABR_OK;
 }
 
@@ -1441,6 +1513,15 @@ extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+#ifdef ABR_ASYNC_STATS
+extern "C" int abr_debug_async_stats(unsigned long long *out48, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_async_stats), 48 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_async_stats), z, sizeof(z)); }
     return 0;
 }
 #endif
@@ -1877,7 +1958,6 @@ static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
     // (T=36): 7 lanes/WG 319 us, 16 lanes/WG (9 waves) 481 us, 3 lanes/WG 365 us per 65 536 lanes.
     int lpb = 256 / T;
     if (lpb > kMpcLanesPerBlock) lpb = kMpcLanesPerBlock;
-    if (const char *e = getenv("ABR_MPC_LPB")) { int v = atoi(e); if (v >= 1 && v < lpb) lpb = v; }  // tuning knob
     if (lpb < 1) lpb = 1;
     const int threads = ((lpb * T + 63) / 64) * 64;
     const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);

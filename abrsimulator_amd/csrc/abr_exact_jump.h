@@ -114,10 +114,8 @@ ABR_HD bool jump_inside(double y, double lim, bool strict) {
 // was off by more than one (astronomically long jumps).  Kept out of line so that
 // the hot path stays small.
 template <int STOP>
-#if defined(__HIPCC__) && !defined(ABR_AB_INLINE_FIX)
+#if defined(__HIPCC__)
 __host__ __device__ __attribute__((noinline))
-#elif defined(__HIPCC__)
-__host__ __device__ inline
 #else
 inline
 #endif
@@ -152,11 +150,7 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
     const int e = expo(x);
     const bool normal = (e > 54) & (e < 2046);
     const int ec = normal ? e : 1000;                // keep the bit tricks in range when unused
-#ifdef ABR_AB_OLD_ABS
-    const double ac = (c < 0.0) ? -c : c;
-#else
     const double ac = (STOP == STOP_GE) ? c : -c;    // |c|: the sign of c is fixed by the stop kind (see chain())
-#endif
     // steady increment of this binade and the tie test (header comment)
     const double base = pow2_biased(ec);
     const double dm = (base + ac) - base;            // RNE(|c| / u) * u

@@ -113,9 +113,10 @@ class BatchedABREnv:
         self._h = h
         if lane_id_base:
             _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
-        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3}
+        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4}
         if impl not in impls:
-            raise ValueError("impl must be 'auto' (default: 'split' up to 131 072 lanes, 'jump' above), "
+            raise ValueError("impl must be 'auto' (default: the fastest at this size, see effective_impl()), "
+                             "'async' (fused rollouts on the asynchronous download/player/service pipeline), "
                              "'split' (role-split event-driven kernels), 'jump' (event-driven, one "
                              "thread per lane) or 'tick'")
         self.impl = impl
@@ -209,6 +210,33 @@ class BatchedABREnv:
                    _lib.ptr(out.get("actions")))
         return out
 
+    def step_script(self, actions, out=None):
+        """len(actions) fused decisions per lane with the ABR controller's answers given up front:
+        actions int32 [n_steps, N] (what run() does with a scripted abr_controller,
+        Simulator.py:155).  Returns dict(obs[n,OBS_DIM,N], reward[n,N], done[n,N])."""
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.int32:
+            a = a.to(torch.int32)
+        a = a.contiguous()
+        if a.dim() != 2 or a.shape[1] != self.n_lanes or a.shape[0] < 1:
+            raise ValueError(f"actions must have shape (n_steps, {self.n_lanes}), got {tuple(a.shape)}")
+        n = int(a.shape[0])
+        if out is None:
+            out = dict(
+                obs=torch.empty(n, OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device),
+                reward=torch.empty(n, self.n_lanes, dtype=torch.float32, device=self.device),
+                done=torch.empty(n, self.n_lanes, dtype=torch.uint8, device=self.device))
+        self._call(self.lib.abr_env_step_script, self._h, n, _lib.ptr(a), _lib.ptr(out.get("obs")),
+                   _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")))
+        return out
+
+    def effective_impl(self, fused: bool = False):
+        """Name of the kernels the handle resolves to right now ('auto' is a policy, not a kernel):
+        fused=True for step_random / step_script, False for step."""
+        v = C.c_int32()
+        _lib.check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
+        return {0: "jump", 1: "tick", 2: "split", 4: "async"}[v.value]
+
     def step_mpc(self, controller, n_steps: int, out=None, want_obs=True, want_actions=True):
         """n_steps decisions per lane taken by `controller` (a BatchedMPCController whose
         tables match this environment) on the device: next_bitrate() on each lane's own
@@ -284,6 +312,9 @@ class BatchedABREnv:
             raise ValueError("workspace size mismatch: different config or lane count")
         self.workspace.copy_(sd["workspace"])
         self.trace_id, self.start_offset = sd["trace_id"], sd["start_offset"]
+        # the handle now carries episodes in flight (a freshly built one had none): the speeds /
+        # bitrate table given to __init__ are in force, later setter calls are latched again
+        _lib.check(self.lib.abr_env_notify_restore(self._h))
 
 
 def obs_dict(obs):

@@ -37,7 +37,11 @@
 extern "C" {
 #endif
 
-#define ABR_ABI_VERSION 1
+/* 2: abr_env_step_script, abr_env_get_effective_impl, impl 4 (asynchronous pipeline); since 1 also:
+ * workspace layout grew, abr_env_set_lane_speeds / _speed_schedule / _bitrate_table are latched
+ * until the next full reset, every re-reset advances the policy's episode counter, default impl
+ * is 3 (auto).  A host built against version 1 must be rebuilt. */
+#define ABR_ABI_VERSION 2
 #define ABR_MAX_RATES 16
 #define ABR_MAX_HORIZON 8
 
@@ -54,6 +58,9 @@ extern "C" {
 #define ABR_DONE_BADACT 0x4     /* action outside [0, n_rates): lane frozen (the reference raises IndexError) */
 #define ABR_DONE_BADARG 0x8     /* abr_env_reset got a trace id outside [0, n_traces) or a negative start
                                    offset for this lane: lane frozen, nothing read out of bounds */
+
+#define ABR_DONE_INTERNAL 0x10  /* the asynchronous pipeline's watchdog fired (a bug in this library, never a
+                                   property of the inputs): the lane is frozen, its later records are void */
 
 /* float32 observation rows written by reset/step: the four arguments of
  * get_next_bitrate (Simulator.py:155) first, then run() locals at that instant */
@@ -131,8 +138,9 @@ int abr_env_set_lane_id_base(abr_env *env, int64_t lane_id_base);
  * speeds_dev: float64 [n_lanes], > 0, must stay valid from this call until the handle is
  * destroyed or another call replaces it.  The pointer is LATCHED: running episodes keep the
  * speeds they started with; the next abr_env_reset picks the new ones up, and that reset must
- * cover all lanes (lane_mask_dev == NULL, else ABR_E_INVALID).  NULL restores the single speed.
- * Event-driven kernels only. */
+ * cover all lanes (lane_mask_dev == NULL, else ABR_E_INVALID).  On a handle that has seen neither
+ * abr_env_reset nor abr_env_notify_restore there is no episode to protect and the call takes
+ * effect at once.  NULL restores the single speed.  Event-driven kernels only. */
 int abr_env_set_lane_speeds(abr_env *env, const double *speeds_dev);   /* latched: see above */
 
 /* What a speed controller answers, call by call (Simulator.py:176-177: get_next_speed() is
@@ -152,13 +160,26 @@ int abr_env_set_speed_schedule(abr_env *env, const double *speeds_dev, int32_t n
  * chunk's ladder.  Latched like abr_env_set_lane_speeds: picked up by the next reset of ALL lanes. */
 int abr_env_set_bitrate_table(abr_env *env, const double *br_table_dev);
 
+/* Resume: the whole simulator state is the workspace, so a checkpoint is a copy of it.  After copying
+ * a checkpointed workspace into the workspace of a handle built with the same config, lane count
+ * and (already set) speeds / bitrate table, call this: it marks the handle as carrying episodes in
+ * flight, so that later setter calls are latched again. */
+int abr_env_notify_restore(abr_env *env);
+
 /* Which kernels serve reset/step: 2 = event-driven (exact closed-form stepping of the
  * float64 tick sequences) with each lane's download side and player side on two waves of one
  * workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per 0.01 s tick;
- * 3 (default) = 2 up to 131 072 lanes, 0 above (whichever is faster at that size).  All
- * produce identical state and outputs (the workspace is interchangeable between them);
- * 1 exists as an independent cross-check. */
+ * 4 = fused rollouts (abr_env_step_random / abr_env_step_script) on the asynchronous
+ * download / player / service pipeline, single steps as 2 (it needs one play speed for all lanes
+ * and video_length <= 1022, else it serves as 2);
+ * 3 (default) = whichever is fastest at this size: 2 up to 131 072 lanes, 0 above (4 is slower
+ * than 2 at every size measured so far and is never picked).  All produce identical state and outputs (the
+ * workspace is interchangeable between them); 1 exists as an independent cross-check. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
+
+/* The implementation (0, 1, 2 or 4) the handle resolves to right now: fused != 0 for
+ * abr_env_step_random / abr_env_step_script, 0 for abr_env_step. */
+int abr_env_get_effective_impl(abr_env *env, int32_t fused, int32_t *impl_out);
 
 /*
  * run() state init (Simulator.py:95-133) plus the idle ticks up to the first
@@ -196,6 +217,16 @@ int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs_out_dev,
 int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed, float *obs_out_dev,
                         float *reward_out_dev, uint8_t *done_out_dev, int32_t *actions_out_dev,
                         void *stream);
+
+/*
+ * n_steps fused decisions per lane whose actions are given up front: actions_dev int32
+ * [n_steps][n_lanes], actions_dev[s][i] = what get_next_bitrate returns at the s-th call site
+ * lane i reaches in this call (Simulator.py:155 with a scripted abr_controller).  Outputs as
+ * abr_env_step_random.  A lane whose scripted action is outside [0, n_rates) is frozen with
+ * ABR_DONE_BADACT at that step, as in abr_env_step.
+ */
+int abr_env_step_script(abr_env *env, int32_t n_steps, const int32_t *actions_dev, float *obs_out_dev,
+                        float *reward_out_dev, uint8_t *done_out_dev, void *stream);
 
 /* calculate_qoe (Simulator.py:79-86) in the reference's operation order from the
  * lane's action history; meaningful for lanes whose episode is complete (with

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(L):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in abr_env.h but not exported"
         assert n in bound, f"{n} declared in abr_env.h but not bound in _lib.SYMBOLS"
-    assert lib.abr_abi_version() == 1
+    assert lib.abr_abi_version() == 2 == L.ABI_VERSION
 
 
 def test_struct_layout_matches_header(L):

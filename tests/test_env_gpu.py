@@ -565,3 +565,40 @@ def test_degenerate_shapes_fused_auto_reset(oracle, V, B):
     cfg = oracle.env_cfg(ladder, 2.0, V, 10.0, 2.0, 1.0, meta["weights"], 1.0)
     _, _, fin, _ = oracle.env_batch(cfg, traces, tid, off, last)
     assert np.allclose(qoe, fin["qoe"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("impl", ["split", "jump", "async"])
+def test_resume_into_a_freshly_built_env(oracle, impl):
+    """Checkpoint / resume in a NEW process: env A (speed schedule [rows, N] + per-chunk ladders) steps
+    half an episode; its state_dict() goes into a freshly built env B, which never saw a reset.  Both
+    finish bit-identically, and identically to an uninterrupted run."""
+    import abrsimulator_amd as A
+    rng = np.random.default_rng(123)
+    V, N, B = 10, 300, 4
+    traces = [rng.uniform(0.3, 6.0, 500).astype(np.float32).astype(np.float64) for _ in range(5)]
+    table = np.sort(rng.uniform(0.3, 4.0, (V, B)), axis=1)
+    sched = torch.from_numpy(rng.uniform(0.8, 1.3, (6, N)))
+    tid = torch.from_numpy(rng.integers(0, 5, N).astype(np.int32))
+    off = torch.from_numpy(rng.integers(0, 500, N).astype(np.int32))
+    acts = torch.from_numpy(rng.integers(0, B, (V, N)).astype(np.int32)).cuda()
+
+    def build():
+        mpd = A.MPD(V, 2.0, 12.0, 4.0, [A.Chunk(list(r)) for r in table])
+        return A.BatchedABREnv(mpd, A.QOEMetric(4.3, 1, 1, 0.1), A.NetworkInfo(1.0, traces), N, speed=sched,
+                               impl=impl)
+
+    ref = build(); ref.reset(tid, off)
+    ref_out = ref.step_script(acts)
+    a = build(); a.reset(tid, off)
+    first = a.step_script(acts[:V // 2])
+    sd = a.state_dict()
+    b = build()                                  # never reset: the speeds / ladders must already be in force
+    b.load_state_dict(sd)
+    out_a, out_b = a.step_script(acts[V // 2:]), b.step_script(acts[V // 2:])
+    for k in ("obs", "reward", "done"):
+        assert torch.equal(out_a[k], out_b[k]), k
+        assert torch.equal(torch.cat([first[k], out_b[k]]), ref_out[k]), k
+    fa, fb, fr = a.observe_f64(), b.observe_f64(), ref.observe_f64()
+    for k in fa:
+        assert torch.equal(fa[k], fb[k]) and torch.equal(fb[k], fr[k]), k
+    assert torch.equal(a.episode_qoe(), b.episode_qoe()) and torch.equal(b.episode_qoe(), ref.episode_qoe())
