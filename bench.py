@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
 V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, 20.0, 8.0, 1.0
 WEIGHTS = [4.3, 1.0, 1.0, 0.1]
-N_TRACES, TRACE_LEN = 1024, 1000
+N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000   # (the override is a cache-residency diagnostic)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 

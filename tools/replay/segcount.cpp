@@ -1,0 +1,37 @@
+// Host-side replay of the bench workload through the product's lane functions (abr_lane_jump.h),
+// counting chain segments per decision: STOP_GE = download trips, STOP_LE / STOP_LT = drain trips.
+// Used by tools/replay_model.py to price kernel schedules before they are written.
+#include <stdint.h>
+static thread_local int g_seg[3];
+#define ABR_SEGMENT_HOOK(STOP) (g_seg[STOP]++)
+#include "abr_lane_jump.h"
+#include "abr_tick_tables.h"
+
+extern "C" int seg_episode(double interval, double L, int32_t V, double max_buffer, double start_up,
+                           int32_t max_ticks, const double *ladder, const double *trace, int32_t tlen,
+                           int32_t offset, const int32_t *actions, int32_t *ge_out, int32_t *le_out,
+                           int32_t *ndl_out) {
+    static thread_local abrx::TickTables tt;
+    static thread_local bool have = false;
+    if (!have) {
+        tt = abrx::build_tick_tables(interval, L, 1.0, V, max_ticks, (int32_t)(max_ticks * 0.01 / interval + 4.0));
+        have = true;
+    }
+    abrx::Tables t;
+    t.G = tt.G.data(); t.interval_tick = tt.interval_tick.data(); t.avail_tick = tt.avail_tick.data();
+    t.L = L; t.sd = tt.sd; t.max_buffer = max_buffer; t.start_up_length = start_up; t.V = V;
+    t.max_ticks = max_ticks; t.per_lane_speed = false; t.speed_rows = 0; t.speed_stride = 0; t.speeds = nullptr;
+    abrx::LaneJ s;
+    s.cur.trace = trace; s.cur.tlen = tlen; s.sd = t.sd;
+    abrx::lanej_init(s, t, offset);
+    if (!abrx::lanej_wait_call(s, t)) return -2;
+    for (int step = 0; step < V; step++) {
+        g_seg[0] = g_seg[1] = g_seg[2] = 0;
+        const int32_t k0 = s.k;
+        abrx::StepResult sr = abrx::lanej_step(s, t, ladder[actions[step]] * L, actions[step]);
+        if (sr.timeout) return -2;
+        ge_out[step] = g_seg[0]; le_out[step] = g_seg[1] + g_seg[2];
+        ndl_out[step] = s.k - k0;
+    }
+    return 0;
+}

@@ -1,0 +1,80 @@
+"""Prices K1 schedules on the host before a kernel is written: replays the bench workload through the
+product's own lane functions (tools/replay/segcount.cpp counts chain segments per decision) and runs
+wave-level schedule models over the per-lane counts:
+  split      one decision per iteration, the wave pays the slowest of its 64 lanes (the shipped kernel)
+  capped(T)  at most T download trips per iteration; a lane that is not done carries its download over
+  flat       no rendezvous at all: mean trips (the bound of any schedule)
+    python tools/replay_model.py [lanes]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import bench as B  # noqa: E402
+from oracle.oracle import philox_action  # noqa: E402  (tools may use the oracle's numpy twin of the policy)
+
+so = os.path.join(R, "tools", "replay", "libsegcount.so")
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I",
+                       os.path.join(R, "abrsimulator_amd", "csrc"), os.path.join(R, "tools", "replay", "segcount.cpp"),
+                       "-o", so])
+lib = C.CDLL(so)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+traces = B.synth_traces(False)
+tid, off = B.lane_assignment(0, N, traces)
+V = B.V
+ge = np.zeros((N, V), np.int32); le = np.zeros((N, V), np.int32); nd = np.zeros((N, V), np.int32)
+lad = (C.c_double * 16)(*B.LADDER)
+acts = np.stack([philox_action(1, np.arange(N), s, 0, len(B.LADDER)) for s in range(V)], 1).astype(np.int32)
+for i in range(N):
+    t = np.ascontiguousarray(traces[tid[i]])
+    rc = lib.seg_episode(C.c_double(B.INTERVAL), C.c_double(B.L), V, C.c_double(B.MAX_BUFFER), C.c_double(B.START_UP),
+                         32 * V * 400, lad, t.ctypes.data_as(C.c_void_p), len(t), int(off[i]),
+                         acts[i].ctypes.data_as(C.c_void_p), ge[i].ctypes.data_as(C.c_void_p),
+                         le[i].ctypes.data_as(C.c_void_p), nd[i].ctypes.data_as(C.c_void_p))
+    assert rc == 0
+print(f"{N} lanes x {V} decisions: download trips mean {ge.mean():.2f} p50 {np.median(ge):.0f} p90 {np.percentile(ge, 90):.0f} "
+      f"p99 {np.percentile(ge, 99):.0f} max {ge.max()};  drain segments mean {le.mean():.2f} p90 {np.percentile(le, 90):.0f} max {le.max()}")
+for a in range(6):
+    print(f"  action {a}: download trips mean {ge[acts == a].mean():.2f}  drain segments {le[acts == a].mean():.2f}")
+W = N // 64
+g = ge.reshape(W, 64, V)
+l = le.reshape(W, 64, V)
+print(f"split: D trips per iteration (max over 64 lanes) {g.max(1).mean():.2f};  P drain segments per iteration "
+      f"{l.max(1).mean():.2f};  per-lane means {ge.mean():.2f} / {le.mean():.2f}")
+
+
+def capped(T, start_cost, trip_cost):
+    """iterations and D cost per decision with at most T trips per iteration"""
+    iters = tot_trips = 0
+    lanes_done = 0
+    for w in range(W):
+        rem = g[w, :, 0].astype(np.int64).copy()
+        step = np.zeros(64, np.int64)
+        while (step < V).any():
+            act = step < V
+            run = int(min(T, rem[act].max()))
+            tot_trips += run
+            iters += 1
+            rem = rem - run
+            fin = act & (rem <= 0)
+            lanes_done += int(fin.sum())
+            step[fin] += 1
+            nxt = fin & (step < V)
+            rem[nxt] = g[w, nxt, step[nxt]]
+            rem[fin & ~nxt] = 0
+    it = iters / W
+    return it / V, tot_trips / W / V, (tot_trips * trip_cost + iters * start_cost) / W / V
+
+
+print("capped(T): iterations/decision, D trips/decision, D cost/decision (trip = 118 + 25, start/validate = 400 instr)")
+base = None
+for T in (4, 6, 8, 10, 12, 14, 16, 64):
+    it, tr, cost = capped(T, 400, 143)
+    if T == 64:
+        base = cost
+    print(f"  T={T:3d}: {it:.3f} iterations  {tr:6.2f} trips  D cost {cost:7.0f}")
+print(f"  (T=64 is the shipped schedule: {base:.0f})")
