@@ -52,7 +52,8 @@ class MpcConfig(C.Structure):
 class MpcOptions(C.Structure):
     _fields_ = [("predictor", C.c_int32), ("utility", C.c_int32), ("hist_dev", C.c_void_p),
                 ("hist_stride", C.c_int64), ("hist_len_dev", C.c_void_p),
-                ("scratch_dev", C.c_void_p), ("scratch_bytes", C.c_size_t)]
+                ("scratch_dev", C.c_void_p), ("scratch_bytes", C.c_size_t),
+                ("mask_is_done", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class StateView(C.Structure):

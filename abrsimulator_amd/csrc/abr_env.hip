@@ -1823,17 +1823,17 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     extern __shared__ double lds[];
     const int B = BC ? BC : p.B;
     const int HB = H * B;
-    // layout per lane-in-block: brv[HB] rbt[HB] tdl[HB] pred[H] | then bestJ[T], bestF[T]
+    // layout per lane-in-block: brv[HB] rbt[HB] tdl[HB] pred[H]
     const int per_lane = 3 * HB + H;
     double *tab = lds;
-    double *bestJ = lds + LPB * per_lane;
-    int32_t *bestF = (int32_t *)(bestJ + LPB * T);
     __shared__ int32_t heff_s[16];
     __shared__ int32_t prev_s[16];    // previous_bitrate as the index Python would use (mpc.py:132,148)
-
+    __shared__ unsigned long long bestK[16];   // phase 4: the lane's maximum of x = -J as an ordered key
+    __shared__ int32_t bestF[16];              //          and the smallest flat index that reaches it
     const int tid = threadIdx.x;
     const int li = tid / T;               // lane in block
     const int pre = tid - li * T;         // prefix id
+    if (threadIdx.x < 16) { bestK[threadIdx.x] = 0; bestF[threadIdx.x] = 0x7fffffff; }
     const int64_t lane = (int64_t)blockIdx.x * LPB + li;
     const bool valid = (li < LPB) && (lane < p.n_lanes) &&
                        !(p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0)));
@@ -1934,34 +1934,31 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             }
         }
     }
-    if (li < LPB) { bestJ[li * T + pre] = best.x; bestF[li * T + pre] = best.idx; }
-    __syncthreads();
     // ---- phase 4: first arg-max of x = -J over the T prefixes of a lane (ascending prefix =
-    //      ascending flat index), then the winning leaf inside the winning group ----
+    //      ascending flat index), then the winning leaf inside the winning group.  Two LDS atomics
+    //      and two barriers: the maximum of x as an order-preserving 64-bit key (ds_max_u64), then
+    //      the smallest flat index among the threads that hold it (ds_min_i32) -- the same winner
+    //      as a left-to-right scan with strict `>` (round 2 used a pairwise tree: six barriers).
+    //      x + 0.0 folds -0.0 into +0.0 so that equal values have equal keys; a NaN never wins. ----
     if (!valid && pre == 0 && li < LPB && lane < p.n_lanes && p.mask_is_done)
         p.action_out[lane] = -1;          // a finished lane of the fused rollout takes no decision
-    // pairwise tree over the lane's T entries: an entry beats another if it is valid and has the
-    // larger x, or the same x and the smaller flat index (= the serial left-to-right scan with
-    // strict `>`: ascending prefix is ascending flat index)
+    unsigned long long key = 0;
     {
-        int tp2 = 1;
-        while (tp2 < T) tp2 <<= 1;
-        for (int sft = tp2 >> 1; sft > 0; sft >>= 1) {
-            if (li < LPB && pre < sft && pre + sft < T) {
-                const int ia = li * T + pre, ib = ia + sft;
-                const int32_t fa = bestF[ia], fb = bestF[ib];
-                const double xa = bestJ[ia], xb = bestJ[ib];
-                const bool take = (fb != 0x7fffffff) &&
-                                  ((fa == 0x7fffffff) || (xb > xa) || (xb == xa && fb < fa));
-                if (take) { bestJ[ia] = xb; bestF[ia] = fb; }
-            }
-            __syncthreads();
-        }
+        const double xc = best.x + 0.0;
+        const unsigned long long u = (unsigned long long)__double_as_longlong(xc);
+        key = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+        if (!(xc == xc) || best.idx == 0x7fffffff) key = 0;
     }
+    if (li < LPB && key) atomicMax(&bestK[li], key);
+    __syncthreads();
+    if (li < LPB && key && key == bestK[li]) atomicMin(&bestF[li], best.idx);
+    __syncthreads();
     if (valid && pre == 0) {
-        const double bx = bestJ[li * T];
-        int32_t bf = bestF[li * T];
-        const bool have = bf != 0x7fffffff;
+        const unsigned long long bk = bestK[li];
+        const unsigned long long bu = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
+        const double bx = __longlong_as_double((long long)bu);
+        int32_t bf = bestF[li];
+        const bool have = bk != 0 && bf != 0x7fffffff;
         const int he = heff_s[li];
         int32_t act = -1;
         if (have) {
@@ -2002,7 +1999,9 @@ static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
     if (lpb < 1) lpb = 1;
     const int threads = ((lpb * T + 63) / 64) * 64;
     const size_t per_lane = (size_t)(3 * H * p.B + H) * sizeof(double);
-    const size_t lds = lpb * per_lane + (size_t)lpb * T * (sizeof(double) + sizeof(int32_t));
+    const size_t lds = lpb * per_lane;
+    // (a persistent grid striding over the lane groups was measured and lost: -8 % at 1 024 workgroups,
+    // -2 % at 2 048 -- the hardware's dynamic dispatch fills the tail better; profiles/r03_ab_mpc.txt)
     const unsigned grid = (unsigned)((p.n_lanes + lpb - 1) / lpb);
     hipLaunchKernelGGL((mpc_select_kernel<H, BC, WVM>), dim3(grid), dim3(threads), lds, st, p, T, D, lpb);
 }
@@ -2093,6 +2092,7 @@ static int apply_mpc_options(MpcParams &p, const abr_mpc_options *opt) {
     if (opt->predictor == ABR_PREDICT_EXPSMOOTHING && (!opt->hist_dev || !opt->hist_len_dev || opt->hist_stride < 1))
         return fail(ABR_E_INVALID, "exponential smoothing needs the history itself: hist_dev, hist_stride, hist_len_dev");
     p.predictor = opt->predictor; p.utility = opt->utility;
+    p.mask_is_done = opt->mask_is_done != 0;
     p.hist = opt->hist_dev; p.hist_stride = opt->hist_stride; p.hist_len = opt->hist_len_dev;
     if (opt->scratch_dev && opt->scratch_bytes < mpc_scratch_bytes(p.H, p.n_lanes))
         return fail(ABR_E_WORKSPACE, "MPC scratch has %zu bytes, need %zu", (size_t)opt->scratch_bytes,

@@ -101,7 +101,11 @@ class BatchedMPCController:
         action = torch.empty(N, dtype=torch.int32, device=self.device)
         flat = torch.empty(N, dtype=torch.int32, device=self.device) if want_details else None
         J = torch.empty(N, dtype=torch.float64, device=self.device) if want_details else None
-        mask = getattr(ci, "mask", None)
+        # `mask`: lanes with a zero byte are skipped; `done`: an environment's ABR_DONE_* bytes as they
+        # are (lanes with a NON-zero byte are skipped) -- no host-side tensor work to turn one into the other
+        mask, mask_is_done = getattr(ci, "mask", None), 0
+        if mask is None and getattr(ci, "done", None) is not None:
+            mask, mask_is_done = ci.done, 1
         for t, dt in ((ci.chunk_number, torch.int32), (ci.previous_bitrate, torch.int32),
                       (ci.buffer_level, torch.float64), (ci.hist_n, torch.float64),
                       (ci.hist_sum_inv, torch.float64)):
@@ -109,6 +113,7 @@ class BatchedMPCController:
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
         opt = _lib.MpcOptions()
         opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
+        opt.mask_is_done = mask_is_done
         if self.use_scratch:
             # scratch for the predictor pre-kernel (include/abr_env.h: abr_mpc_options.scratch_dev)
             need = C.c_size_t()
@@ -174,7 +179,7 @@ class EnvPlayer:
         ci = EnvPlayer._Info()
         ci.chunk_number, ci.previous_bitrate = self.chunk_id, self.last_bitrate
         ci.buffer_level, ci.hist_n, ci.hist_sum_inv = self.buffer_level, self.hist_n, self.hist_sum_inv
-        ci.mask = (self.done == 0).to(torch.uint8)
+        ci.done = self.done            # the kernel reads the done bits themselves (abr_mpc_options.mask_is_done)
         # the list itself, for predictors that need more than its harmonic summary (f4):
         # previous_bandwidths[t, i] for t < chunk_id[i]
         ci.previous_bandwidths = self.env.history()[1]

@@ -290,8 +290,8 @@ def main():
 
         def run(n_steps, timed):
             for _ in range(n_steps):
-                if not drive_env:
-                    player.hist_n.copy_(hist_n0); player.hist_sum_inv.copy_(hist_s0)
+                # (no history restore between selects: every call grows the lanes' throughput history by
+                # `horizon` predictions, D9, exactly as repeated next_bitrate() calls do in the reference)
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 if drive_env:

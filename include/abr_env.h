@@ -333,6 +333,10 @@ typedef struct abr_mpc_options {
                                      per lane, instead of on 1 of the lane's n_rates^2 search threads: same
                                      results, ~10 % less time.  NULL: everything in one kernel. */
     size_t scratch_bytes;
+    int32_t mask_is_done;         /* != 0: lane_mask_dev holds ABR_DONE_* bits (an environment's `done` array, as
+                                     is): a lane is skipped iff its byte is NON-zero, and reports action -1.
+                                     0: lane_mask_dev is a plain mask, lanes with a zero byte are skipped */
+    int32_t reserved_;
 } abr_mpc_options;
 
 /* Bytes of scratch abr_mpc_options.scratch_dev needs for n_lanes at cfg->horizon. */
