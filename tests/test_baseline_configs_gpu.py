@@ -170,6 +170,82 @@ def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr, path):
         assert np.array_equal(f[k].cpu().numpy(), fin[k]), k
 
 
+def _rollout_vs_oracle(oracle, env, ctl, traces, tid, off, br, sz, wv, wr, pick, H=5):
+    """V fused MPC-driven decisions on every lane of `env`; the sampled lanes `pick` replayed through the
+    oracle composition (run() whose plug-in is next_bitrate() on run()'s own lists; the wiring itself
+    -- shared history incl. the D9 samples, D13 -> bitrate 0, D12 clip -- is build-defined, both
+    halves are pinned to the reference)."""
+    out = env.step_mpc(ctl, V, want_obs=False)
+    d = out["done"].cpu().numpy()
+    assert (d[:-1] == 0).all() and (d[-1] == 1).all()                 # every lane: exactly one episode
+    a_all = out["actions"].cpu().numpy()
+    assert a_all.min() >= 0 and a_all.max() < 6
+    ecfg = oracle.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
+    mcfg = oracle.mpc_cfg(6, H, V, L, MAX_BUFFER, wv, wr, 0.0)
+    steps, bw, acts, fin = oracle.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid[pick], off[pick], threads=16)
+    assert np.array_equal(a_all[:, pick].T, acts)
+    assert np.array_equal(env.history()[1].cpu().numpy()[:, pick].T, bw)
+    assert np.allclose(env.episode_qoe().cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
+    f = env.observe_f64()
+    for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
+        assert np.array_equal(f[k].cpu().numpy()[pick], fin[k]), k
+    # size-independent property on EVERY lane: sum(reward) + wl * average_latency == calculate_qoe
+    rew = out["reward"].double().sum(0).cpu().numpy()
+    qoe = env.episode_qoe().cpu().numpy()
+    assert np.allclose(rew + WEIGHTS[3] * f["average_latency"].cpu().numpy(), qoe, rtol=1e-5)
+    return acts
+
+
+def test_config2_mpc_rollout_65536_lanes_full_episodes(oracle):
+    """BASELINE.json configs[2] composed, at its real size: 65 536 envs x MPC horizon 5 over 6 rates,
+    48-chunk episodes driven by abr_env_step_mpc (Simulator.py:155 x mpc.py:181-186), 1 100+ sampled
+    lanes incl. the first and last workgroups == the oracle composition."""
+    import abrsimulator_amd as A
+    from abrsimulator_amd.sharding import lane_assignment
+    N = 65536
+    traces = _traces()
+    tid, off = lane_assignment(0, N, [len(t) for t in traces])
+    env = make_env(META, traces, N)
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    br = np.tile(np.array(LADDER), (V, 1))
+    sz = br * L                                                          # the bench's CBR tables
+    mpd = A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(list(b), list(s)) for b, s in zip(br, sz)])
+    ctl = A.BatchedMPCController(A.EnvPlayer(env, mpd=mpd, qoe=A.QOEMetric(4.3, 1.0, 0.0)), horizon=5)
+    rng = np.random.default_rng(22)
+    pick = np.unique(np.concatenate([np.arange(14), np.arange(N - 14, N), [63, 64, 127, 128],
+                                     rng.integers(0, N, 1100)]))
+    assert len(pick) >= 1024
+    _rollout_vs_oracle(oracle, env, ctl, traces, tid, off, br, sz, 1.0, 4.3, pick)
+
+
+def test_config4_shard_shape_131072_lanes_mixed_traces_mpc_rollout(oracle):
+    """BASELINE.json configs[4], the per-rank shape of the 8-GPU job: rank 7's 131 072 lanes
+    (lane_id_base = 7 * 131072: the lane -> (trace, offset) map is a function of the GLOBAL lane id),
+    mixed 300-3 000-point traces (wrap-around: the divergent while-loop stress), MPC-driven rollout
+    on VBR tables; 1 000+ sampled lanes == the oracle composition."""
+    import abrsimulator_amd as A
+    from abrsimulator_amd.sharding import lane_assignment, shard_range
+    lane0, N = shard_range(1048576, 8, 7)
+    assert (lane0, N) == (7 * 131072, 131072)
+    traces = _traces(1024, mixed=True, seed=4)
+    lens = [len(t) for t in traces]
+    tid, off = lane_assignment(lane0, N, lens)
+    env = make_env(META, traces, N, lane_id_base=lane0)
+    assert env.effective_impl() == "split"
+    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    rng = np.random.default_rng(44)
+    br = np.array(LADDER)[None, :] * rng.uniform(0.8, 1.2, (V, 6))
+    sz = br * L * rng.uniform(0.7, 1.3, (V, 6))
+    mpd = A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(list(b), list(s)) for b, s in zip(br, sz)])
+    ctl = A.BatchedMPCController(A.EnvPlayer(env, mpd=mpd, qoe=A.QOEMetric(0.3, 0.5, 0.0)), horizon=5)
+    pick = np.unique(np.concatenate([np.arange(14), np.arange(N - 14, N), rng.integers(0, N, 1050)]))
+    assert len(pick) >= 1024
+    acts = _rollout_vs_oracle(oracle, env, ctl, traces, tid, off, br, sz, 0.5, 0.3, pick)
+    assert len(np.unique(acts)) == 6                                  # every rate is exercised
+    fin_t = env.observe_f64()["global_time"].cpu().numpy()
+    assert (fin_t > np.array(lens)[tid] - off).any()                  # lanes wrapped around their trace (D7)
+
+
 # ---------------------------------------------------------------------------------------------
 # N > 1: two ranks, HIP shards, the product's collective
 # ---------------------------------------------------------------------------------------------
