@@ -396,7 +396,10 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                 p.trace_id[i] = t; p.offset0[i] = offset0;
                 s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
                 lane_init(s, p, offset0);
-                if (done) { active = false; s.running = false; }
+                if (done) {            // frozen (BADARG): still report the fresh lane's observation, as every implementation does
+                    write_obs(s, p, i, obs_out, 0.0);
+                    active = false; s.running = false;
+                }
             }
         } else {
             done = p.done[i];
@@ -780,7 +783,7 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// K1, role-split form (impl 2, the default for step / step_random)
+// K1, role-split form (impl 2; what impl 3 = auto resolves to up to kSplitMaxLanes lanes)
 // ---------------------------------------------------------------------------
 // Measured on MI355X (profiles/r02_valu_cost_microbench.txt): ONE wave on a SIMD issues a
 // vector instruction every 4.1-4.5 cycles (float64: 5.4-6.4) however independent its
@@ -1077,6 +1080,14 @@ __device__ __forceinline__ void split_role_player(
 
 // MODE 1: one externally supplied action per lane; MODE 2: fused random-policy rollout;
 // MODE 3: fused rollout of scripted actions [n_steps][n_lanes]
+//
+// Barrier discipline: the per-iteration workgroup barrier sits at two call sites, one in each role
+// function, reached through the wave-uniform branch below.  That is well defined on this target -- a
+// wave is entirely in one role, s_barrier counts WAVES, and both role loops execute exactly one barrier
+// per iteration and leave in the same iteration (the exit flag is written before the barrier and read by
+// both after it) -- but it relies on the branch staying wave-uniform: never split a role across a wave.
+// A mismatch would show as a hang, which the max_ticks / timeout parity tests (tests/test_env_gpu.py:
+// test_timeouts_are_identical_on_every_implementation, tests/test_async_gpu.py) turn into a failure.
 template <int MODE>
 __global__ __launch_bounds__(128) void env_split_kernel(
     EnvParams p, const int32_t *__restrict__ actions, float *__restrict__ obs_out,

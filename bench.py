@@ -3,7 +3,8 @@
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
-  BASELINE.json's 1/2/4/8-GPU scaling curve on 1 048 576 lanes: add --total-lanes 1048576.
+  BASELINE.json's 1/2/4/8-GPU scaling curve on 1 048 576 lanes is measured in the same process and
+  reported under "strong_1048576" (or run only that job with --total-lanes 1048576).
 
 Workloads (config.workload in the JSON line)
   env_random  (default; BASELINE.json configs[1]) 65 536 lanes per GPU, built-in
@@ -42,6 +43,8 @@ LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
 V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, 20.0, 8.0, 1.0
 WEIGHTS = [4.3, 1.0, 1.0, 0.1]
 N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000   # (the override is a cache-residency diagnostic)
+STRONG_TOTAL = int(os.environ.get("ABR_BENCH_STRONG_TOTAL", "1048576"))   # configs[3] / north_star: the scaling
+                               # curve's job size (the override exists for the 2-rank rehearsal test)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
@@ -175,8 +178,9 @@ def _load_traffic(workload, kernel, lanes, fuse):
         t = json.load(open(tj)).get(workload)
     except Exception:
         return None
-    if t and t.get("fuse") == fuse and t.get("lanes") == lanes and t.get("kernel") == kernel:
-        return t
+    for e in (t if isinstance(t, list) else [t]):      # one entry per profiled (kernel, lanes, fuse)
+        if e and e.get("fuse") == fuse and e.get("lanes") == lanes and e.get("kernel") == kernel:
+            return e
     return None
 
 
@@ -204,6 +208,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="env_random, N=1: skip the MPC combos/s half of BASELINE.json's metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="env_random: skip the strong_1048576 block (BASELINE.json configs[3]: 1 048 576 lanes "
+                         "split over the ranks of this run)")
     ap.add_argument("--graph", action="store_true",
                     help="env_random, N=1: capture one launch in a HIP graph and replay it "
                          "(removes the host launch path; matters at --fuse 1)")
@@ -303,59 +310,61 @@ def main():
                     events.append((e0, e1, 1))
         return run
 
-    if a.workload == "env_random":
-        F = max(1, min(a.fuse, K))            # decisions actually fused into one launch
-        slabs = [make_slab(F, OBS_DIM, N, dev) for _ in range(2)]
-        bufs = [dict(obs=o, reward=r, done=torch.empty(F, N, dtype=torch.uint8, device=dev), actions=None)
+    def make_random_runner(env_, N_, F_, events_, use_graph):
+        """The env_random step loop over `env_`: launches of F_ fused decisions into double-buffered
+        slabs; with more than one rank THE one collective of the path per launch -- ONE all-gather of
+        the packed slab [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with
+        the next launch.  The intermediate observations of a fused launch are consumed on-device by the
+        built-in policy and stay in the local slab; at --fuse 1 every observation is gathered
+        (configs[3] literally)."""
+        slabs = [make_slab(F_, OBS_DIM, N_, dev) for _ in range(2)]
+        bufs = [dict(obs=o, reward=r, done=torch.empty(F_, N_, dtype=torch.uint8, device=dev), actions=None)
                 for (_, o, r, _) in slabs]
         gather = (world > 1 or force_dist) and not a.no_gather
-        if gather:
-            # THE one collective of the path: per launch, ONE all-gather of the packed slab
-            # [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with the
-            # next launch (double-buffered).  The intermediate observations of a fused launch are
-            # consumed on-device by the built-in policy and stay in the local slab; at --fuse 1
-            # every observation is gathered (configs[3] literally).
-            gat = ObsRewardGather((OBS_DIM, N), (F, N), dev)
-
+        gat_ = ObsRewardGather((OBS_DIM, N_), (F_, N_), dev) if gather else None
         graph = None
-        if a.graph and world == 1:
+        if use_graph:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                env.step_random(F, a.seed, out=bufs[0])   # warm-up on a side stream before capture
+                env_.step_random(F_, a.seed, out=bufs[0])   # warm-up on a side stream before capture
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                env.step_random(F, a.seed, out=bufs[0])
+                env_.step_random(F_, a.seed, out=bufs[0])
 
-        def run(n_steps, timed):
+        def run_(n_steps, timed):
             left, it = n_steps, 0
-            while graph is not None and left >= F:
+            while graph is not None and left >= F_:
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 graph.replay()
                 if timed:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
-                    ev.append((e0, e1, F))
-                left -= F
+                    events_.append((e0, e1, F_))
+                left -= F_
             while left > 0:
-                f = min(F, left)
+                f = min(F_, left)
                 b = it & 1
                 if gather:
-                    gat.wait_free(b)                      # slab b has been gathered: reusable
+                    gat_.wait_free(b)                     # slab b has been gathered: reusable
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
-                env.step_random(f, a.seed, out=bufs[b] if f == F else None)
+                env_.step_random(f, a.seed, out=bufs[b] if f == F_ else None)
                 if timed:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
-                    ev.append((e0, e1, f))
-                if gather and f == F:
-                    gat.gather(b, slabs[b][3])
+                    events_.append((e0, e1, f))
+                if gather and f == F_:
+                    gat_.gather(b, slabs[b][3])
                 left -= f
                 it += 1
             if gather:
-                gat.finish()
+                gat_.finish()
+        return run_, gat_
 
+    if a.workload == "env_random":
+        F = max(1, min(a.fuse, K))            # decisions actually fused into one launch
+        run, gat = make_random_runner(env, N, F, ev, a.graph and world == 1)
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"
     else:
@@ -455,6 +464,32 @@ def main():
                                 "combos_per_lane": 6 ** 5, "predictor": "harmonic"},
                      "roofline": mpc_roofline(ls2)}
 
+    # ---- BASELINE.json configs[3] / north_star "1/2/4/8-GPU scaling curve on 1 048 576 lanes": the SAME job
+    #      split over however many ranks this run has, measured in this process after the headline metric
+    #      (which stays 65 536 lanes per GPU so that N = 1 is BENCH's number).  The driver's back-to-back
+    #      N = 1, 2, 4, 8 runs therefore yield both curves: `value` (weak) and `strong_1048576.value`. ----
+    strong = None
+    if a.workload == "env_random" and not a.total_lanes and not a.no_strong and STRONG_TOTAL % world == 0:
+        lane0s, Ns = shard_range(STRONG_TOTAL, world, rank)
+        tids, offs = lane_assignment(lane0s, Ns, traces)
+        env_s = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), Ns, device=dev,
+                                auto_reset=True, lane_id_base=lane0s, impl=a.impl)
+        env_s.reset(torch.from_numpy(tids), torch.from_numpy(offs))
+        ev_s = []
+        run_s, gat_s = make_random_runner(env_s, Ns, F, ev_s, False)
+        run_s(min(W, 2 * F), False)
+        reps_s = max(1, min(repeats, 12))
+        times_s = [timed_region(run_s, K) for _ in range(reps_s)]
+        el_s = float(np.median(times_s))
+        ls_s, _ = launch_stats(ev_s)
+        strong = {"metric": "env_steps_per_sec", "value": STRONG_TOTAL * K / el_s, "unit": "env-steps/s",
+                  "scaling": "strong", "n_gpus": world, "total_lanes": STRONG_TOTAL, "lanes_per_gpu": Ns,
+                  "steps": K, "ms_per_step": el_s / K * 1e3, "repeats": reps_s, "fuse": F,
+                  "impl": env_s.effective_impl(fused=True), "avg_launch_us": ls_s * 1e6,
+                  "collective": (f"1 all_gather_into_tensor per launch, {(8 + F) * Ns * 4} B per rank; issued "
+                                 f"{gat_s.n_collectives}x" if gat_s else "none")}
+        del env_s
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(traces, a.seed)
@@ -484,6 +519,8 @@ def main():
         }
         if secondary is not None:
             line["secondary"] = secondary
+        if strong is not None:
+            line["strong_1048576"] = strong
         print(json.dumps(line))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -290,16 +290,24 @@ def test_reset_with_bad_trace_id_or_offset_freezes_the_lane():
     import abrsimulator_amd as A
     from abrsimulator_amd import _lib
     traces = _traces(4, seed=1)
-    env = make_env(dict(META, video_length=4), traces, 128)
-    tid = (torch.arange(128, dtype=torch.int32) % 4).cuda()
-    off = torch.zeros(128, dtype=torch.int32).cuda()
-    tid[3] = 4; tid[9] = -1; off[17] = -5                    # through the C ABI, past env.reset's checks
-    _lib.check(env.lib.abr_env_reset(env._h, _lib.ptr(tid), _lib.ptr(off), None, _lib.ptr(env.obs),
-                                     _lib.current_stream(env.device)))
-    a = torch.zeros(128, dtype=torch.int32).cuda()
-    _, _, done = env.step(a)
-    d = done.cpu().numpy()
-    assert (d[[3, 9, 17]] == _lib.DONE_BADARG).all() and (np.delete(d, [3, 9, 17]) == 0).all()
+    obs0 = {}
+    for impl in ("split", "jump", "tick", "async"):
+        env = make_env(dict(META, video_length=4), traces, 128, impl=impl)
+        env.obs.fill_(-7.0)                                  # stale bytes must not survive in a frozen lane's row
+        tid = (torch.arange(128, dtype=torch.int32) % 4).cuda()
+        off = torch.zeros(128, dtype=torch.int32).cuda()
+        tid[3] = 4; tid[9] = -1; off[17] = -5                # through the C ABI, past env.reset's checks
+        _lib.check(env.lib.abr_env_reset(env._h, _lib.ptr(tid), _lib.ptr(off), None, _lib.ptr(env.obs),
+                                         _lib.current_stream(env.device)))
+        obs0[impl] = env.obs.clone()
+        # a frozen lane reports the fresh-lane observation (tick 0: nothing downloaded, start-up running)
+        assert torch.equal(obs0[impl][:, [3, 9, 17]].cpu(),
+                           torch.tensor([0, -1, 0, 0, 0, 0, 0, 0.01], dtype=torch.float32)[:, None].expand(8, 3))
+        a = torch.zeros(128, dtype=torch.int32).cuda()
+        _, _, done = env.step(a)
+        d = done.cpu().numpy()
+        assert (d[[3, 9, 17]] == _lib.DONE_BADARG).all() and (np.delete(d, [3, 9, 17]) == 0).all()
+        assert torch.equal(obs0[impl], obs0["split"]), impl
     with pytest.raises(ValueError):
         env.reset(tid.cpu(), off.cpu())                      # the Python front end refuses outright
 
@@ -474,3 +482,27 @@ def test_bench_rccl_code_path_with_one_rank():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert "backend nccl" in line["config"]["collective"] and line["config"]["collective"].endswith("issued 3x")
     assert line["value"] > 0
+    # the scaling-curve job (BASELINE.json configs[3]) rides in the same line: 1 048 576 lanes on this one rank
+    st = line["strong_1048576"]
+    assert st["total_lanes"] == 1048576 and st["lanes_per_gpu"] == 1048576 and st["scaling"] == "strong"
+    assert st["value"] > line["value"] and st["collective"].endswith("issued 3x")
+
+
+def test_bench_default_line_carries_both_scaling_curves_two_ranks():
+    """What the driver's SCALE run launches (bare `bench.py --gpus N`), rehearsed with two gloo ranks on this
+    box's one GPU: the headline stays weak scaling at the per-GPU lane count, and the strong-scaling job is
+    split over the ranks (its size shrunk for the rehearsal)."""
+    import json
+    env = dict(os.environ, ABR_BENCH_ONE_DEVICE="1", ABR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               ABR_BENCH_STRONG_TOTAL="16384")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--lanes-per-gpu", "4096", "--min-timed-steps", "40"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_lanes"] == 8192
+    st = line["strong_1048576"]
+    assert st["scaling"] == "strong" and st["total_lanes"] == 16384 and st["lanes_per_gpu"] == 8192
+    assert st["n_gpus"] == 2 and st["value"] > 0 and st["collective"].startswith("1 all_gather_into_tensor")
