@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise the round's evidence from gpurun_out/r02/ (scratch, written by tools/gpu_r02_final.sh on
+"""Summarise the round's evidence from gpurun_out/r03/ (scratch, written by tools/gpu_r03_final.sh on
 the GPU box) into profiles/ (tracked): rocprofv3 kernel stats, PMC summaries, bench JSON lines.
 
   python tools/collect_profiles.py --stage DIR   on the GPU box: DIR/*/.../*.csv -> DIR/summary.json
-  python tools/collect_profiles.py               here: gpurun_out/r02/ -> profiles/r02_*
+  python tools/collect_profiles.py               here: gpurun_out/r03/ -> profiles/r03_*
 """
 import argparse
 import collections
@@ -14,7 +14,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r02"
+TAG = "r03"
 ENV_KERNEL = "env_split_kernel<2>"
 MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
 LANES, FUSE = 65536, 48
@@ -38,83 +38,97 @@ def stats(path):
     return out
 
 
+ENV_RUNS = (("env", 48), ("env_f20", 20))     # (directory tag, decisions per launch): default bench, driver's --steps 20
+
+
 def stage(O):
-    s = {"stats_env": stats(O + "/stats_env"), "stats_mpc": stats(O + "/stats_mpc"),
-         "stats_env_mpc": stats(O + "/stats_env_mpc")}
-    for k in ("fetch_env", "write_env", "fetch_mpc", "write_mpc", "sq_env_g1", "sq_env_g2", "sq_env_g3"):
+    s = {"stats_mpc": stats(O + "/stats_mpc"), "stats_env_mpc": stats(O + "/stats_env_mpc")}
+    for tag, _ in ENV_RUNS:
+        s["stats_" + tag] = stats(O + "/stats_" + tag)
+        for k in ("fetch_", "write_"):
+            s[k + tag] = counters(O + "/" + k + tag)
+        for g in (1, 2, 3):
+            s[f"sq_{tag}_g{g}"] = counters(O + f"/sq_{tag}_g{g}")
+    for k in ("fetch_mpc", "write_mpc"):
         s[k] = counters(O + "/" + k)
     json.dump(s, open(O + "/summary.json", "w"), indent=1)
-    print(json.dumps({k: list(v)[:4] for k, v in s.items()}, indent=1)[:2000])
+    print(json.dumps({k: list(v)[:4] for k, v in s.items()}, indent=1)[:2500])
 
 
 def collect():
-    G, P = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles")
+    G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
     s = json.load(open(os.path.join(G, "summary.json")))
-    for src, dst in (("bench_default.json", "bench_default.json"), ("bench_driver_args.json", "bench_driver_args.json"),
-                     ("bench_mpc.json", "bench_mpc.json"), ("bench_env_mpc.json", "bench_env_mpc.json"),
-                     ("sweeps.txt", "sweeps.txt"), ("role_stamps.txt", "role_stamps.txt")):
+    for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "sweeps.txt",
+                "role_stamps.txt", "async_role_stats.txt"):
         if os.path.exists(os.path.join(G, src)):
-            shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{dst}"))
-    for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_mpc", "mpc_kernel_stats.csv"),
-                      ("stats_env_mpc", "env_mpc_kernel_stats.csv")):
+            shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
+    for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),
+                      ("stats_mpc", "mpc_kernel_stats.csv"), ("stats_env_mpc", "env_mpc_kernel_stats.csv")):
         fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True))
         if fs:
             shutil.copy(fs[-1], os.path.join(P, f"{TAG}_{dst}"))
-    json.dump({k: s[k] for k in ("fetch_env", "write_env", "fetch_mpc", "write_mpc")},
-              open(os.path.join(P, f"{TAG}_hbm_pmc_summary.json"), "w"), indent=1)
+    keys = [k + t for t, _ in ENV_RUNS for k in ("fetch_", "write_")] + ["fetch_mpc", "write_mpc"]
+    json.dump({k: s[k] for k in keys}, open(os.path.join(P, f"{TAG}_hbm_pmc_summary.json"), "w"), indent=1)
     # ---- HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read) ----
-    src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_r02_final.sh), "
+    src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_r03_final.sh), "
            "per-launch averages in KB; FETCH_SIZE doubled (gfx950 reports half of a coalesced read, "
            "MI355X_MICROARCH.md 'HBM'; our 4-8 B/lane reads are outside the calibrated 16 B/lane case, "
            "so the read side is an upper estimate), WRITE_SIZE as read")
-    traffic = {}
-    for wl, kern, f, w, fuse in (("env_random", ENV_KERNEL, "fetch_env", "write_env", FUSE),
-                                 ("mpc", MPC_KERNEL, "fetch_mpc", "write_mpc", 1)):
-        fk = [k for k in s[f] if k.startswith(kern.split("<")[0]) and (kern in k or wl == "mpc")]
+    traffic = {"env_random": []}
+
+    def entry(kern, f, w, fuse, pick):
+        fk = [k for k in s[f] if pick(k)]
         if not fk:
-            continue
+            return None
         k = fk[0]
         fe, nf = s[f][k]["FETCH_SIZE"]
         wr, _ = s[w][k]["WRITE_SIZE"]
-        traffic[wl] = {"fuse": fuse, "lanes": LANES, "kernel": kern.replace(", 1>", ">").replace(", ", ","),
-                       "profiled_kernel": k, "launches": nf, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr,
-                       "bytes_per_launch": (2 * fe + wr) * 1024,
-                       "source": f"profiles/{TAG}_hbm_pmc_summary.json: " + src}
+        return {"fuse": fuse, "lanes": LANES, "kernel": kern, "profiled_kernel": k, "launches": nf,
+                "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "bytes_per_launch": (2 * fe + wr) * 1024,
+                "source": f"profiles/{TAG}_hbm_pmc_summary.json ({f}, {w}): " + src}
+    for tag, fuse in ENV_RUNS:
+        e = entry(ENV_KERNEL, "fetch_" + tag, "write_" + tag, fuse, lambda k: k.startswith(ENV_KERNEL))
+        if e:
+            traffic["env_random"].append(e)
+    e = entry("mpc_select_kernel<5,6>", "fetch_mpc", "write_mpc", 1, lambda k: k.startswith("mpc_select_kernel"))
+    if e:
+        traffic["mpc"] = e
     json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
-    # ---- SQ counters of the env kernel and what binds it ----
-    c = {}
-    for g in ("sq_env_g1", "sq_env_g2", "sq_env_g3"):
-        for k, v in s[g].items():
-            if k.startswith(ENV_KERNEL):
-                c.update({n: m for n, (m, _) in v.items()})
-    ks = [v for k, v in s["stats_env"].items() if k.startswith(ENV_KERNEL)]
-    if c and ks:
-        waves = c["SQ_WAVES"]
-        n_simd = 1024
-        dur_s = ks[0]["avg_ns"] * 1e-9
+    # ---- SQ counters of the env kernel and what binds it, per profiled fuse ----
+    for tag, fuse in ENV_RUNS:
+        c = {}
+        for g in (1, 2, 3):
+            for k, v in s[f"sq_{tag}_g{g}"].items():
+                if k.startswith(ENV_KERNEL):
+                    c.update({n: m for n, (m, _) in v.items()})
+        ks = [v for k, v in s["stats_" + tag].items() if k.startswith(ENV_KERNEL)]
+        if not (c and ks):
+            continue
+        waves, n_simd, dur_s = c["SQ_WAVES"], 1024, ks[0]["avg_ns"] * 1e-9
         valu_per_simd = c["SQ_INSTS_VALU"] / n_simd
         derived = {
             "waves_per_launch": waves,
-            "valu_insts_per_lane_group_per_decision": c["SQ_INSTS_VALU"] / (LANES / 64) / FUSE,
-            "salu_insts_per_lane_group_per_decision": c["SQ_INSTS_SALU"] / (LANES / 64) / FUSE,
-            "lds_insts_per_lane_group_per_decision": c["SQ_INSTS_LDS"] / (LANES / 64) / FUSE,
-            "wave_cycles_per_decision": c["SQ_WAVE_CYCLES"] * 4 / waves / FUSE,
+            "valu_insts_per_lane_group_per_decision": c["SQ_INSTS_VALU"] / (LANES / 64) / fuse,
+            "salu_insts_per_lane_group_per_decision": c["SQ_INSTS_SALU"] / (LANES / 64) / fuse,
+            "lds_insts_per_lane_group_per_decision": c["SQ_INSTS_LDS"] / (LANES / 64) / fuse,
+            "wave_cycles_per_decision": c["SQ_WAVE_CYCLES"] * 4 / waves / fuse,
             "wait_fraction": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
             "active_fraction": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
             "avg_active_lanes_per_valu_inst": c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]}
-        binding = {"resource": "valu_issue",
+        binding = {"resource": "valu_issue (one wave's dependent float64 stream per SIMD pair: see DESIGN.md section 4)",
                    "frac": valu_per_simd * 4.0 / (dur_s * 2.4e9),
                    "active_lanes": derived["avg_active_lanes_per_valu_inst"],
                    "valu_insts_per_simd_per_launch": valu_per_simd, "kernel_us": dur_s * 1e6,
                    "definition": "vector instructions per SIMD per launch x 4 cycles / (kernel time x 2.4 GHz); "
                                  "active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
-        json.dump({"kernel": ENV_KERNEL, "lanes": LANES, "fuse": FUSE,
-                   "config": f"{LANES} lanes, fuse {FUSE}, two waves (download role, player role) per 64 lanes",
+        json.dump({"kernel": ENV_KERNEL, "lanes": LANES, "fuse": fuse,
+                   "config": f"{LANES} lanes, fuse {fuse}, two waves (download role, player role) per 64 lanes",
                    "per_launch_average": c, "derived": derived, "binding": binding},
-                  open(os.path.join(P, f"{TAG}_env_split_sq_counters.json"), "w"), indent=1)
-        print("binding", binding)
-    print("traffic", {k: v["bytes_per_launch"] for k, v in traffic.items()})
-    print("kernel stats", {k: v for k, v in s["stats_env"].items() if "env_" in k})
+                  open(os.path.join(P, f"{TAG}_env_split_fuse{fuse}_sq_counters.json"), "w"), indent=1)
+        print("binding fuse", fuse, binding)
+    print("traffic", {k: (v["bytes_per_launch"] if isinstance(v, dict) else [(e["fuse"], e["bytes_per_launch"]) for e in v])
+                      for k, v in traffic.items()})
+    print("kernel stats", {t: {k: v for k, v in s["stats_" + t].items() if "env_" in k} for t, _ in ENV_RUNS})
 
 
 if __name__ == "__main__":
