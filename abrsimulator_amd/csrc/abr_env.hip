@@ -34,12 +34,12 @@
 // cycles since that wave's previous stamp to region n, in LDS; the totals go to global memory
 // once, at the end of the kernel (ABR_STAMP_FLUSH); read with abr_debug_read_stamps.
 __device__ unsigned long long g_st_acc[32];
-__shared__ unsigned long long g_sh_st[2][33];
+__shared__ unsigned long long g_sh_st[3][33];
 #define ABR_STAMP(n)                                                                           \
     do {                                                                                       \
         if ((threadIdx.x & 63) == 0) {                                                         \
             const unsigned long long t_ = (unsigned long long)__builtin_amdgcn_s_memtime();    \
-            const unsigned w_ = (threadIdx.x >> 6) & 1;                                        \
+            const unsigned w_ = (threadIdx.x >> 6) % 3;                                        \
             g_sh_st[w_][n] += t_ - g_sh_st[w_][32];                                            \
             g_sh_st[w_][32] = t_;                                                              \
         }                                                                                      \
@@ -47,16 +47,16 @@ __shared__ unsigned long long g_sh_st[2][33];
 #define ABR_STAMP_INIT()                                                                       \
     do {                                                                                       \
         if ((threadIdx.x & 63) == 0) {                                                         \
-            for (int q_ = 0; q_ < 32; q_++) g_sh_st[(threadIdx.x >> 6) & 1][q_] = 0;           \
-            g_sh_st[(threadIdx.x >> 6) & 1][32] = (unsigned long long)__builtin_amdgcn_s_memtime(); \
+            for (int q_ = 0; q_ < 32; q_++) g_sh_st[(threadIdx.x >> 6) % 3][q_] = 0;           \
+            g_sh_st[(threadIdx.x >> 6) % 3][32] = (unsigned long long)__builtin_amdgcn_s_memtime(); \
         }                                                                                      \
     } while (0)
 #define ABR_STAMP_FLUSH()                                                                      \
     do {                                                                                       \
         if ((threadIdx.x & 63) == 0)                                                           \
             for (int q_ = 0; q_ < 32; q_++)                                                    \
-                if (g_sh_st[(threadIdx.x >> 6) & 1][q_])                                       \
-                    atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) & 1][q_]);             \
+                if (g_sh_st[(threadIdx.x >> 6) % 3][q_])                                       \
+                    atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]);             \
     } while (0)
 #else
 #define ABR_STAMP_INIT()
@@ -854,8 +854,12 @@ __device__ __forceinline__ void split_role_download(
     const int32_t V = p.video_length;
     // The download wave is the critical one (15.3 k of 16.1 k cycles per iteration); priority outranks
     // age in the SIMD's issue arbitration, so its instructions go first whenever they are ready.
-    // Same box, three interleaved pairs: 417.1 -> 405.1 us per launch (profiles/r03_ab_split_prio_lds.txt)
-    __builtin_amdgcn_s_setprio(1);
+    // Same box, three interleaved pairs: 417.1 -> 405.1 us per launch (profiles/r03_ab_lds_staging.txt (4));
+    // in the three-wave kernel the ORDER D > P > S is worth 8 % (profiles/r03_ab_split3.txt)
+#ifndef ABR_SPLIT_PRIO_D
+#define ABR_SPLIT_PRIO_D 2     // above the player wave (1 in the three-wave kernel, 0 in the two-wave one)
+#endif
+    __builtin_amdgcn_s_setprio(ABR_SPLIT_PRIO_D);
     const abrx::Tables tb = make_tables(p);
     abrx::Cursor cur; cur.j = 0; cur.tpos = 0; cur.tlen = 1; cur.trace = p.traces;
     int32_t snap_j = 0, snap_tpos = 0;             // cursor before the download just issued
@@ -1101,6 +1105,7 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     else split_role_player<MODE>(p, m, obs_out, reward_out, done_out, actions_out, n_total);
 }
 
+#include "abr_env_split3.h"
 #ifndef ABR_AB_LDS_TABLES
 #include "abr_env_async.h"
 #endif
@@ -1359,8 +1364,8 @@ extern "C" int abr_env_destroy(abr_env *env) {
 // 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl < 0 || impl > 4)
-        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 4 (async)");
+    if (impl < 0 || impl > 5)
+        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto), 4 (async) or 5 (split3)");
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -1424,6 +1429,10 @@ static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 // waves (65 536 lanes: 7.2e9 vs 6.2e9 env-steps/s); from 262 144 lanes on the plain form has
 // enough waves of its own and no barrier (1.39e10 vs 1.32e10 at 1 M).  profiles/r02_sweeps.txt
 constexpr int64_t kSplitMaxLanes = 131072;
+// The three-wave form (abr_env_split3.h) wins while all its waves are resident: 3 x 1 024 waves of 101 VGPRs at
+// 65 536 lanes (8.26e9 vs 7.56e9 env-steps/s; 6.86e9 vs 6.34e9 with 20 decisions per launch); at 98 304 lanes and
+// beyond its workgroups no longer fit at once and it loses to the two-wave form.  profiles/r03_ab_split3.txt
+constexpr int64_t kSplit3MaxLanes = 65536;
 // The asynchronous pipeline (abr_env_async.h) serves FUSED rollouts only (a single step has nothing to
 // run ahead of).  Measured on MI355X at 65 536 lanes, fuse 48 (profiles/r03_async_*): 714 us per launch
 // against 418 us for the role-split kernel -- its flat download loop needs 9.75 trips per decision instead
@@ -1443,10 +1452,23 @@ static inline int effective_impl(const abr_env *env, bool fused = false) {
     int impl = env->impl;
     if (impl == 3) {
         if (fused && env->p.n_lanes <= kAsyncMaxLanes && async_eligible(env)) return 4;
+        if (env->p.n_lanes <= kSplit3MaxLanes) return 5;
         return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
     }
     if (impl == 4) return (fused && async_eligible(env)) ? 4 : 2;
     return impl;
+}
+static inline bool is_split(int impl) { return impl == 2 || impl == 5; }
+// launch of the role-split kernels: two waves per 64 lanes (impl 2) or three (impl 5)
+template <int MODE>
+static void launch_split(int impl, const EnvParams &p, const int32_t *actions, float *obs, float *rew, uint8_t *dn,
+                         int32_t *acts, int32_t n_steps, uint64_t seed, hipStream_t st) {
+    if (impl == 5)
+        hipLaunchKernelGGL(env_split3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(192), 0, st, p, actions, obs, rew,
+                           dn, acts, n_steps, seed);
+    else
+        hipLaunchKernelGGL(env_split_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(128), 0, st, p, actions, obs, rew,
+                           dn, acts, n_steps, seed);
 }
 
 extern "C" int abr_env_reset(abr_env *env, const int32_t *trace_id_dev,
@@ -1474,10 +1496,9 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (!actions_dev) return fail(ABR_E_INVALID, "actions_dev is NULL");
     const int impl = effective_impl(env);
-    if (impl == 2)
-        hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(128), 0,
-                           (hipStream_t)stream, env->p, actions_dev, obs_out_dev, reward_out_dev,
-                           done_out_dev, nullptr, 1, 0ull);
+    if (is_split(impl))
+        launch_split<1>(impl, env->p, actions_dev, obs_out_dev, reward_out_dev, done_out_dev, nullptr, 1, 0ull,
+                        (hipStream_t)stream);
     else
         hipLaunchKernelGGL(impl ? env_advance_kernel<1> : env_jump_kernel<1>, dim3(grid64(env->p.n_lanes)), dim3(64), 0,
                            (hipStream_t)stream, env->p, actions_dev, nullptr, nullptr, nullptr,
@@ -1506,9 +1527,8 @@ static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, ui
         }
     } else
 #endif
-    if (impl == 2)
-        hipLaunchKernelGGL(env_split_kernel<MODE>, dim3(grid64(N)), dim3(128), 0, st, env->p, script, obs, rew,
-                           dn, acts, n_steps, seed);
+    if (is_split(impl))
+        launch_split<MODE>(impl, env->p, script, obs, rew, dn, acts, n_steps, seed, st);
     else
         hipLaunchKernelGGL(impl ? env_advance_kernel<MODE> : env_jump_kernel<MODE>, dim3(grid64(N)), dim3(64), 0,
                            st, env->p, script, nullptr, nullptr, nullptr, obs, rew, dn, acts, n_steps, seed);
@@ -2181,9 +2201,8 @@ extern "C" int abr_env_step_mpc(abr_env *env, const abr_mpc_config *cfg,
         float *obs = obs_out_dev ? obs_out_dev + (int64_t)s * ABR_OBS_DIM * N : nullptr;
         float *rew = reward_out_dev ? reward_out_dev + (int64_t)s * N : nullptr;
         uint8_t *dn = done_out_dev ? done_out_dev + (int64_t)s * N : nullptr;
-        if (effective_impl(env) == 2)
-            hipLaunchKernelGGL(env_split_kernel<1>, dim3(grid64(N)), dim3(128), 0, st, env->p, act, obs, rew,
-                               dn, nullptr, 1, 0ull);
+        if (is_split(effective_impl(env)))
+            launch_split<1>(effective_impl(env), env->p, act, obs, rew, dn, nullptr, 1, 0ull, st);
         else
             hipLaunchKernelGGL(env_jump_kernel<1>, dim3(grid64(N)), dim3(64), 0, st, env->p, act, nullptr,
                                nullptr, nullptr, obs, rew, dn, nullptr, 1, 0ull);

@@ -48,6 +48,7 @@ class BatchedABREnv:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("BatchedABREnv runs on a ROCm device only (no CPU path exists)")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.n_lanes = int(n_lanes)
         self.mpd, self.qoe_metric, self.network_info = mpd, qoe_metric, network_info
         # one ladder for the whole video (what run() indexes, Simulator.py:82,156) or, for an MPD
@@ -113,12 +114,12 @@ class BatchedABREnv:
         self._h = h
         if lane_id_base:
             _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
-        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4}
+        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4, "split3": 5}
         if impl not in impls:
             raise ValueError("impl must be 'auto' (default: the fastest at this size, see effective_impl()), "
                              "'async' (fused rollouts on the asynchronous download/player/service pipeline), "
-                             "'split' (role-split event-driven kernels), 'jump' (event-driven, one "
-                             "thread per lane) or 'tick'")
+                             "'split' / 'split3' (role-split event-driven kernels, two / three waves per 64 lanes), "
+                             "'jump' (event-driven, one thread per lane) or 'tick'")
         self.impl = impl
         _lib.check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:
@@ -139,8 +140,11 @@ class BatchedABREnv:
     def _call(self, fn, *args):
         """One C-ABI call with self.device current: the library launches on the stream it is
         handed, and HIP launches go to the CURRENT device."""
-        with torch.cuda.device(self.device):
+        if torch.cuda.current_device() == self._dev_index:     # the common case: no context switch to pay
             _lib.check(fn(*args, self._stream()))
+        else:
+            with torch.cuda.device(self.device):
+                _lib.check(fn(*args, self._stream()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -235,7 +239,7 @@ class BatchedABREnv:
         fused=True for step_random / step_script, False for step."""
         v = C.c_int32()
         _lib.check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
-        return {0: "jump", 1: "tick", 2: "split", 4: "async"}[v.value]
+        return {0: "jump", 1: "tick", 2: "split", 4: "async", 5: "split3"}[v.value]
 
     def step_mpc(self, controller, n_steps: int, out=None, want_obs=True, want_actions=True):
         """n_steps decisions per lane taken by `controller` (a BatchedMPCController whose

@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--impl", default="auto", choices=["auto", "async", "split", "jump", "tick"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "async", "split", "split3", "jump", "tick"])
     ap.add_argument("--min-timed-steps", type=int, default=960,
                     help="when --steps is smaller than this the timed region of exactly --steps steps is "
                          "repeated (each repeat bracketed by barrier + synchronize) and the MEDIAN repeat "
@@ -269,7 +269,8 @@ def main():
                           auto_reset=True, lane_id_base=lane0, impl=a.impl)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
     impl = env.effective_impl(fused=True)      # what the library resolves --impl to for fused rollouts
-    env_kernel = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "jump": "env_jump_kernel<2>",
+    env_kernel = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>",
+                  "jump": "env_jump_kernel<2>",
                   "tick": "env_advance_kernel<2>"}[impl]
 
     def barrier():
@@ -333,14 +334,23 @@ def main():
             with torch.cuda.graph(graph):
                 env_.step_random(F_, a.seed, out=bufs[0])
 
+        pool = []      # HIP events are created on their first record(): do that outside the timed region
+
+        def take():
+            return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+
         def run_(n_steps, timed):
             left, it = n_steps, 0
+            if not timed:                                 # warm-up call: stock the pool for the timed calls
+                need = 2 * (max(1, -(-a.min_timed_steps // max(K, 1))) + 1) * (K // F_ + 2)
+                while len(pool) < need:
+                    e = torch.cuda.Event(enable_timing=True); e.record(); pool.append(e)
             while graph is not None and left >= F_:
                 if timed:
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    e0 = take(); e0.record()
                 graph.replay()
                 if timed:
-                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    e1 = take(); e1.record()
                     events_.append((e0, e1, F_))
                 left -= F_
             while left > 0:
@@ -349,10 +359,10 @@ def main():
                 if gather:
                     gat_.wait_free(b)                     # slab b has been gathered: reusable
                 if timed:
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    e0 = take(); e0.record()
                 env_.step_random(f, a.seed, out=bufs[b] if f == F_ else None)
                 if timed:
-                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    e1 = take(); e1.record()
                     events_.append((e0, e1, f))
                 if gather and f == F_:
                     gat_.gather(b, slabs[b][3])

@@ -172,8 +172,10 @@ int abr_env_notify_restore(abr_env *env);
  * 4 = fused rollouts (abr_env_step_random / abr_env_step_script) on the asynchronous
  * download / player / service pipeline, single steps as 2 (it needs one play speed for all lanes
  * and video_length <= 1022, else it serves as 2);
- * 3 (default) = whichever is fastest at this size: 2 up to 131 072 lanes, 0 above (4 is slower
- * than 2 at every size measured so far and is never picked).  All produce identical state and outputs (the
+ * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
+ * time, history, reward, observation, episode end);
+ * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 131 072 lanes,
+ * 0 above (4 is slower than 2 at every size measured so far and is never picked).  All produce identical state and outputs (the
  * workspace is interchangeable between them); 1 exists as an independent cross-check. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 

@@ -16,7 +16,7 @@ from helpers import F64_EXACT, make_env, philox_action
 
 pytestmark = pytest.mark.gpu
 
-FUSED_IMPLS = ["async", "split", "jump"]
+FUSED_IMPLS = ["async", "split3", "split", "jump"]
 
 
 def _obs_expect(rec, s):
@@ -260,11 +260,14 @@ def test_async_falls_back_with_per_lane_speeds():
 
 
 def test_auto_resolves_to_the_measured_fastest():
-    """`auto` is a measured choice: role-split up to 131 072 lanes for single steps and fused
-    rollouts alike; the asynchronous pipeline is opt-in."""
+    """`auto` is a measured choice: the three-wave role-split kernel up to 65 536 lanes, the
+    two-wave one up to 131 072, one thread per lane above -- for single steps and fused rollouts alike;
+    the asynchronous pipeline is opt-in."""
     rng = np.random.default_rng(6)
     traces = _bench_like(rng, n_traces=4)
     env = make_env(BENCH_META, traces, 512)
+    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
+    env = make_env(BENCH_META, traces, 65537)
     assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "split"
 
 

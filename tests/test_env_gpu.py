@@ -35,7 +35,7 @@ def _cmp_step(f64, g, s, name):
     assert np.array_equal((fl >> 2) & 1, g["buffer_full"][:, s])
 
 
-IMPLS = ["split", "jump", "tick"]   # role-split (default), one-thread-per-lane, tick-by-tick cross-check
+IMPLS = ["split", "split3", "jump", "tick"]   # role-split (2 / 3 waves per 64 lanes), one-thread-per-lane, tick-by-tick cross-check
 
 
 @pytest.mark.parametrize("impl", IMPLS)

@@ -15,7 +15,7 @@ import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = "r03"
-ENV_KERNEL = "env_split_kernel<2>"
+ENV_KERNEL = "env_split3_kernel<2>"
 MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
 LANES, FUSE = 65536, 48
 
@@ -59,7 +59,7 @@ def collect():
     G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
     s = json.load(open(os.path.join(G, "summary.json")))
     for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "sweeps.txt",
-                "role_stamps.txt", "async_role_stats.txt"):
+                "role_stamps.txt", "role_stamps_split3.txt", "async_role_stats.txt"):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
     for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),
@@ -122,9 +122,9 @@ def collect():
                    "definition": "vector instructions per SIMD per launch x 4 cycles / (kernel time x 2.4 GHz); "
                                  "active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
         json.dump({"kernel": ENV_KERNEL, "lanes": LANES, "fuse": fuse,
-                   "config": f"{LANES} lanes, fuse {fuse}, two waves (download role, player role) per 64 lanes",
+                   "config": f"{LANES} lanes, fuse {fuse}, three waves (download, player, service roles) per 64 lanes",
                    "per_launch_average": c, "derived": derived, "binding": binding},
-                  open(os.path.join(P, f"{TAG}_env_split_fuse{fuse}_sq_counters.json"), "w"), indent=1)
+                  open(os.path.join(P, f"{TAG}_env_split3_fuse{fuse}_sq_counters.json"), "w"), indent=1)
         print("binding fuse", fuse, binding)
     print("traffic", {k: (v["bytes_per_launch"] if isinstance(v, dict) else [(e["fuse"], e["bytes_per_launch"]) for e in v])
                       for k, v in traffic.items()})

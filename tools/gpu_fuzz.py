@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Config-space fuzz on the GPU box: random configurations (chunk lengths, trace intervals, ladders,
 buffer limits, start-up lengths, ragged traces with wrap-around) x random features (one speed, one
-speed per lane, a speed schedule, per-chunk ladders) x kernel implementation, every lane's
+speed per lane, a speed schedule, per-chunk ladders) x kernel implementation (role-split, one thread per
+lane, asynchronous pipeline -- which serves the speed features through the role-split kernels) x call form
+(V single steps, or one fused scripted rollout), every lane's
 previous_bandwidths (float64 ==), final clocks / buffer / play_time (==), play_id (==) and episode
 QoE (1e-10) against the C oracle.   usage: python tools/gpu_fuzz.py [n_seeds] [lanes]"""
 import json
@@ -34,7 +36,8 @@ for seed in range(n_seeds):
     off = np.array([rng.integers(0, lens[t]) for t in tid], np.int32)
     actions = rng.integers(0, B, (N, V)).astype(np.int32)
     feature = ["plain", "lane_speeds", "schedule", "vbr", "schedule+vbr"][seed % 5]
-    impl = ["split", "jump"][(seed // 5) % 2]
+    impl = ["split", "jump", "async"][(seed // 5) % 3]
+    fused = (seed // 15) % 2 == 1 or impl == "async"    # one abr_env_step_script call instead of V abr_env_step calls
     speeds, br = None, None
     if "lane_speeds" in feature:
         speeds = rng.choice([0.6, 0.8, 1.0, 1.25, 1.7, 0.9173], N)
@@ -53,8 +56,11 @@ for seed in range(n_seeds):
                           speed=sp, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
     acts = torch.from_numpy(actions).cuda()
-    for s in range(V):
-        env.step(acts[:, s].contiguous())
+    if fused:
+        env.step_script(acts.T.contiguous())
+    else:
+        for s in range(V):
+            env.step(acts[:, s].contiguous())
     f = {k: v.cpu().numpy() for k, v in env.observe_f64().items()}
     b = int((env.history()[1].cpu().numpy().T != bw).sum())
     for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
@@ -66,7 +72,8 @@ for seed in range(n_seeds):
         print("MISMATCH seed", seed, feature, impl, b, meta)
     bad += b
     lane_steps += N * V
-    feats[feature + "/" + impl] = feats.get(feature + "/" + impl, 0) + 1
+    key = feature + "/" + impl + ("/fused" if fused else "")
+    feats[key] = feats.get(key, 0) + 1
     env.close()
 print(json.dumps(dict(seeds=n_seeds, lanes_per_seed=N, lane_steps=lane_steps, mismatches=bad,
                       cases=feats, seconds=round(time.time() - t0, 1),

@@ -24,15 +24,16 @@ S="--no-cpu-baseline --no-secondary --no-strong"
 for F in 1 16 20 48; do python bench.py --steps 960 --warmup 96 --fuse $F $S 2>/dev/null | line fuse; done
 for N in 131072 262144 1048576; do python bench.py --steps 480 --warmup 96 --lanes-per-gpu $N $S 2>/dev/null | line lanes; done
 python bench.py --mixed-traces --steps 960 --warmup 96 $S 2>/dev/null | line mixed_traces_300_3000
-for I in async jump tick; do python bench.py --impl $I --steps 480 --warmup 96 $S 2>/dev/null | line other_impl; done
+for I in split async jump tick; do python bench.py --impl $I --steps 480 --warmup 96 $S 2>/dev/null | line other_impl; done
 python bench.py --impl async --lanes-per-gpu 16384 --steps 480 --warmup 96 $S 2>/dev/null | line other_impl
 python bench.py --impl split --lanes-per-gpu 16384 --steps 480 --warmup 96 $S 2>/dev/null | line other_impl
 python bench.py --impl jump --lanes-per-gpu 1048576 --steps 480 --warmup 96 $S 2>/dev/null | line other_impl
 echo "sweeps done"
 make -C abrsimulator_amd/csrc -s libabr_hip_stamps.so libabr_hip_astats.so 2>/dev/null   # diagnostic builds (not built by __graft_entry__.build)
-ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 > $O/role_stamps.txt 2>&1 || true
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 split > $O/role_stamps.txt 2>&1 || true
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 split3 > $O/role_stamps_split3.txt 2>&1 || true
 ABR_HIP_LIB=libabr_hip_astats.so python tools/gpu_async_stats.py 65536 48 > $O/async_role_stats.txt 2>&1 || true
-tail -3 $O/role_stamps.txt; cat $O/async_role_stats.txt
+tail -22 $O/role_stamps_split3.txt; cat $O/async_role_stats.txt
 exit 0
 fi
 cd /tmp && export TMPDIR=/tmp

@@ -16,22 +16,25 @@ from abrsimulator_amd import _lib  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 traces = B.synth_traces(False)
 tid, off = B.lane_assignment(0, N, traces)
+IMPL = sys.argv[2] if len(sys.argv) > 2 else "split"
 env = A.BatchedABREnv(A.MPD(B.V, B.L, B.MAX_BUFFER, B.START_UP, A.Chunk(B.LADDER)), A.QOEMetric(*B.WEIGHTS),
-                      A.NetworkInfo(B.INTERVAL, traces), N, auto_reset=True)
+                      A.NetworkInfo(B.INTERVAL, traces), N, auto_reset=True, impl=IMPL)
 env.reset(torch.from_numpy(tid), torch.from_numpy(off))
 for _ in range(3):
     env.step_random(48, 1, want_actions=False)
 torch.cuda.synchronize()
-fn = env.lib.abr_debug_stamp_row
-fn.restype = C.c_void_p
-fn.argtypes = [C.c_void_p]
-row = env._view(fn(env._h), torch.float64, (N,)).cpu().numpy().reshape(-1, 64)[:, :6]
-names = ["D work", "D wait", "D iters", "P work", "P wait", "P iters"]
-for c, n in enumerate(names):
-    print(f"{n:8s} mean {row[:, c].mean():12.0f}  min {row[:, c].min():12.0f}  max {row[:, c].max():12.0f}")
-it = row[:, 2].mean()
-print(f"per iteration: D work {row[:,0].mean()/it:.0f} wait {row[:,1].mean()/it:.0f} | "
-      f"P work {row[:,3].mean()/it:.0f} wait {row[:,4].mean()/it:.0f} cycles; iterations/launch {it:.1f}")
+print("impl", IMPL)
+if IMPL == "split":
+    fn = env.lib.abr_debug_stamp_row
+    fn.restype = C.c_void_p
+    fn.argtypes = [C.c_void_p]
+    row = env._view(fn(env._h), torch.float64, (N,)).cpu().numpy().reshape(-1, 64)[:, :6]
+    names = ["D work", "D wait", "D iters", "P work", "P wait", "P iters"]
+    for c, n in enumerate(names):
+        print(f"{n:8s} mean {row[:, c].mean():12.0f}  min {row[:, c].min():12.0f}  max {row[:, c].max():12.0f}")
+    it = row[:, 2].mean()
+    print(f"per iteration: D work {row[:,0].mean()/it:.0f} wait {row[:,1].mean()/it:.0f} | "
+          f"P work {row[:,3].mean()/it:.0f} wait {row[:,4].mean()/it:.0f} cycles; iterations/launch {it:.1f}")
 
 rd = env.lib.abr_debug_read_stamps
 rd.argtypes = [C.c_void_p, C.c_int]
@@ -43,6 +46,7 @@ waves = N // 64
 regions = {1: "D begin_step loads", 2: "D philox", 3: "D download loop", 4: "D publish", 5: "D barrier wait",
            0: "D validate+loop", 9: "P record read", 10: "P drain (download ticks)", 11: "P completing tick",
            12: "P phase B wait_call", 13: "P return", 14: "P div+hist+reward", 15: "P episode end", 16: "P obs out",
-           17: "P feedback", 18: "P barrier wait", 8: "P loop"}
+           17: "P feedback", 18: "P barrier wait", 8: "P loop",
+           20: "S loop", 21: "S service (split3)", 22: "S barrier wait"}
 for k in sorted(regions):
     print(f"  [{k:2d}] {regions[k]:28s} {buf[k] / waves / 49:9.0f} cycles / wave / iteration")
