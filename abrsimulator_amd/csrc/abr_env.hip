@@ -811,6 +811,10 @@ struct SplitMail {
     // P -> D, double-buffered by iteration parity
     int32_t fb_step[2][64], fb_k[2][64], fb_chunk[2][64], fb_episode[2][64], fb_alive[2][64];
     int32_t any_alive[2];
+    // three-wave kernel only (abr_env_split3.h): the policy's draws for launch steps [act_lo, act_hi), made
+    // ahead by the service wave; act[step % 64][lane].  0 / 0 = nothing there (the two-wave kernel).
+    uint8_t act[64][64];
+    int32_t act_lo, act_hi;
 };
 constexpr int kRecValid = 1, kRecHit = 2, kRecBadAct = 4;
 
@@ -844,7 +848,7 @@ __device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, in
 
 // Wave 0 of a workgroup: the download side of its 64 lanes.  Executes exactly one workgroup
 // barrier per iteration, as split_role_player does, and leaves the loop in the same iteration.
-template <int MODE>
+template <int MODE, bool ACT_RING = false>
 __device__ __forceinline__ void split_role_download(
     const EnvParams &p, SplitMail &m, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, int32_t n_total, uint64_t seed) {
@@ -892,6 +896,7 @@ __device__ __forceinline__ void split_role_download(
             int32_t a;
             if (MODE == 1) a = actions[i];
             else if (MODE == 3) a = actions[(int64_t)d_step * p.n_lanes + i];
+            else if (ACT_RING && d_step >= m.act_lo && d_step < m.act_hi) a = m.act[d_step & 63][l];   // drawn ahead by S
             else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
                                             (uint32_t)d_ep, (uint32_t)p.n_rates);
             if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;

@@ -113,7 +113,7 @@ template <int MODE>
 __device__ __forceinline__ void split3_role_service(
     const EnvParams &p, SplitMail &m, SplitMail2 &m2, float *__restrict__ obs_out,
     float *__restrict__ reward_out, uint8_t *__restrict__ done_out, int32_t *__restrict__ actions_out,
-    int32_t n_total) {
+    int32_t n_total, uint64_t seed) {
     const int l = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 64 + l;
     const bool in_range = i < p.n_lanes;
@@ -204,11 +204,41 @@ __device__ __forceinline__ void split3_role_service(
         if (speeds) o_pt = m2.pt[sl][l];
         write_obs_now(obs);
     };
+    // ---- the policy's draws, made ahead of the download wave (this wave idles most of an iteration) ----
+    // Launch step s of a lane is chunk (chunk0 + s) of its episode sequence whatever is redone on the way, so
+    // the draw of step s is known up front.  act[s % 64] may be overwritten once every lane still running is
+    // past step s, i.e. steps below lo + 64 with lo = the slowest live lane's step (P's fb_step, one iteration
+    // old); D never waits for an entry -- one that is not there it draws itself.
+    int32_t a_next = 0, a_chunk = o_chunk, a_ep = episode_no;      // next step to draw, and its (chunk, episode)
+    auto draw_ahead = [&](const int32_t lo, const int32_t count) {
+        if (MODE != 2) return;
+        int32_t hi = lo + 60;
+        if (hi > n_total) hi = n_total;
+        for (int32_t q = 0; q < count && a_next < hi; q++) {
+            const uint32_t a = philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)a_chunk, (uint32_t)a_ep,
+                                             (uint32_t)p.n_rates);
+            m.act[a_next & 63][l] = (uint8_t)a;
+            a_next++; a_chunk++;
+            if (a_chunk >= V) { a_chunk = 0; a_ep++; }
+        }
+        if (l == 0) { m.act_lo = a_next > 64 ? a_next - 64 : 0; m.act_hi = a_next; }
+    };
     int last_cb = 0;
     ABR_STAMP_INIT();
     for (int32_t t = 0;; t++) {
         const int cb = t & 1, pb = (t + 1) & 1;
         ABR_STAMP(20);
+        {
+            // the slowest live lane's step, as P published it in the previous iteration
+            int32_t lo = 0;
+            if (t >= 1) {
+                lo = m.fb_alive[pb][l] ? m.fb_step[pb][l] : 0x7fffffff;
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) { const int32_t o2 = __shfl_xor(lo, sh, 64); lo = o2 < lo ? o2 : lo; }
+                if (lo == 0x7fffffff) lo = n_total;
+            }
+            draw_ahead(lo, t == 0 ? 4 : 3);
+        }
         if (t >= 1 && in_range) service(pb);       // what P finished in the previous iteration
         last_cb = cb;
         ABR_STAMP(21);
@@ -249,9 +279,15 @@ __global__ __launch_bounds__(192) void env_split3_kernel(
     __shared__ SplitMail2 m2;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     ABR_STAGE_TABLES(p);
-    if (threadIdx.x < 64) split_role_download<MODE>(p, m, actions, actions_out, n_total, seed);
+    if (threadIdx.x == 0) { m.act_lo = 0; m.act_hi = 0; }
+    __syncthreads();
+#ifndef ABR_AB_NO_ACT_RING
+    if (threadIdx.x < 64) split_role_download<MODE, true>(p, m, actions, actions_out, n_total, seed);
+#else
+    if (threadIdx.x < 64) split_role_download<MODE, false>(p, m, actions, actions_out, n_total, seed);
+#endif
     else if (threadIdx.x < 128) split3_role_player<MODE>(p, m, m2, n_total);
-    else split3_role_service<MODE>(p, m, m2, obs_out, reward_out, done_out, actions_out, n_total);
+    else split3_role_service<MODE>(p, m, m2, obs_out, reward_out, done_out, actions_out, n_total, seed);
 }
 
 #endif
