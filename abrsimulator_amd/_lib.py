@@ -152,5 +152,11 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device):
+    """The caller's current HIP stream on `device` as a void* (the fast raw accessor when torch has it)."""
+    if _raw_stream is not None and device.index is not None:
+        return C.c_void_p(_raw_stream(device.index))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -30,6 +30,13 @@ def pack_traces(traces: Sequence, device):
     return flat.to(device), off.to(device), lens.to(device)
 
 
+class BoundOut(dict):
+    """An output dict of step_random / step_script whose device pointers have been looked up once
+    (BatchedABREnv.bind_out): a launch per call is then a ctypes call and nothing else.  The tensors
+    must not be replaced afterwards."""
+    ptrs = None
+
+
 class BatchedABREnv:
     """n_lanes independent players, one per GPU thread.
 
@@ -48,7 +55,9 @@ class BatchedABREnv:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("BatchedABREnv runs on a ROCm device only (no CPU path exists)")
-        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._dev_index = self.device.index
         self.n_lanes = int(n_lanes)
         self.mpd, self.qoe_metric, self.network_info = mpd, qoe_metric, network_info
         # one ladder for the whole video (what run() indexes, Simulator.py:82,156) or, for an MPD
@@ -209,10 +218,20 @@ class BatchedABREnv:
                 done=torch.empty(n, self.n_lanes, dtype=torch.uint8, device=self.device),
                 actions=(torch.empty(n, self.n_lanes, dtype=torch.int32, device=self.device)
                          if want_actions else None))
-        self._call(self.lib.abr_env_step_random, self._h, n, C.c_uint64(int(seed) & (2 ** 64 - 1)),
-                   _lib.ptr(out.get("obs")), _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")),
-                   _lib.ptr(out.get("actions")))
+        ptrs = getattr(out, "ptrs", None)
+        if ptrs is None:
+            ptrs = (_lib.ptr(out.get("obs")), _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")),
+                    _lib.ptr(out.get("actions")))
+        self._call(self.lib.abr_env_step_random, self._h, n, C.c_uint64(int(seed) & (2 ** 64 - 1)), *ptrs)
         return out
+
+    def bind_out(self, out):
+        """Look the device pointers of an output dict (obs / reward / done / actions, any of them None) up
+        once; pass the result as `out=` to step_random."""
+        b = BoundOut(out)
+        b.ptrs = (_lib.ptr(out.get("obs")), _lib.ptr(out.get("reward")), _lib.ptr(out.get("done")),
+                  _lib.ptr(out.get("actions")))
+        return b
 
     def step_script(self, actions, out=None):
         """len(actions) fused decisions per lane with the ABR controller's answers given up front:

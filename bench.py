@@ -319,8 +319,8 @@ def main():
         built-in policy and stay in the local slab; at --fuse 1 every observation is gathered
         (configs[3] literally)."""
         slabs = [make_slab(F_, OBS_DIM, N_, dev) for _ in range(2)]
-        bufs = [dict(obs=o, reward=r, done=torch.empty(F_, N_, dtype=torch.uint8, device=dev), actions=None)
-                for (_, o, r, _) in slabs]
+        bufs = [env_.bind_out(dict(obs=o, reward=r, done=torch.empty(F_, N_, dtype=torch.uint8, device=dev),
+                                   actions=None)) for (_, o, r, _) in slabs]
         gather = (world > 1 or force_dist) and not a.no_gather
         gat_ = ObsRewardGather((OBS_DIM, N_), (F_, N_), dev) if gather else None
         graph = None
