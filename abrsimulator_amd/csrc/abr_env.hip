@@ -62,32 +62,6 @@ __shared__ unsigned long long g_sh_st[3][33];
 #define ABR_STAMP_INIT()
 #define ABR_STAMP_FLUSH()
 #endif
-#ifdef ABR_AB_LDS_TABLES
-// A/B build only (profiles/r03_ab_lds_staging.txt): the two tick tables staged in LDS by every kernel
-// that runs the lane functions, read with ds_read (a generic pointer to LDS would turn the hot loop's
-// read into a flat_load, whose vmcnt(0) wait stalls on the trace prefetch).  The first 2 048 interval
-// ticks (8 KB; a whole 36 KB table leaves room for only 3 workgroups per CU and costs 64 %) and
-// video_length + 2 <= 1024 availability ticks; later intervals fall back to global memory.
-__shared__ int32_t g_lds_itick[2048];
-__shared__ int32_t g_lds_avail[1024];
-__device__ __forceinline__ int32_t ab_itick(const int32_t *g, int32_t i) {
-    int32_t v = g_lds_itick[i < 2048 ? i : 2047];
-    if (i >= 2048) v = *(const volatile int32_t *)(g + i);    // volatile: not to be merged into one flat_load
-    return v;
-}
-#define ABR_ITICK(t, i) ab_itick((t).interval_tick, (i))
-#define ABR_AVAIL(t, i) g_lds_avail[i]
-#define ABR_STAGE_TABLES(p)                                                                              \
-    do {                                                                                                 \
-        for (int q_ = threadIdx.x; q_ < 2048; q_ += blockDim.x)                                          \
-            g_lds_itick[q_] = q_ < (p).n_intervals + 8 ? (p).interval_tick[q_] : INT_MAX;                \
-        for (int q_ = threadIdx.x; q_ < 1024; q_ += blockDim.x)                                          \
-            g_lds_avail[q_] = q_ < (p).video_length + 2 ? (p).avail_tick[q_] : INT_MAX;                  \
-        __syncthreads();                                                                                 \
-    } while (0)
-#else
-#define ABR_STAGE_TABLES(p)
-#endif
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
@@ -655,7 +629,6 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int32_t V = p.video_length;
     const abrx::Tables tb = make_tables(p);
-    ABR_STAGE_TABLES(p);
     LaneJ s;
     bool active = in_range, touched = in_range;
     uint8_t done = 0;
@@ -860,10 +833,7 @@ __device__ __forceinline__ void split_role_download(
     // age in the SIMD's issue arbitration, so its instructions go first whenever they are ready.
     // Same box, three interleaved pairs: 417.1 -> 405.1 us per launch (profiles/r03_ab_lds_staging.txt (4));
     // in the three-wave kernel the ORDER D > P > S is worth 8 % (profiles/r03_ab_split3.txt)
-#ifndef ABR_SPLIT_PRIO_D
-#define ABR_SPLIT_PRIO_D 2     // above the player wave (1 in the three-wave kernel, 0 in the two-wave one)
-#endif
-    __builtin_amdgcn_s_setprio(ABR_SPLIT_PRIO_D);
+    __builtin_amdgcn_s_setprio(2);     // above the player wave (1 in the three-wave kernel, 0 in the two-wave one)
     const abrx::Tables tb = make_tables(p);
     abrx::Cursor cur; cur.j = 0; cur.tpos = 0; cur.tlen = 1; cur.trace = p.traces;
     int32_t snap_j = 0, snap_tpos = 0;             // cursor before the download just issued
@@ -1104,16 +1074,13 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
     __shared__ SplitMail m;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
-    ABR_STAGE_TABLES(p);
     // the role is wave-uniform: each wave runs exactly one of the two loops
     if (threadIdx.x < 64) split_role_download<MODE>(p, m, actions, actions_out, n_total, seed);
     else split_role_player<MODE>(p, m, obs_out, reward_out, done_out, actions_out, n_total);
 }
 
 #include "abr_env_split3.h"
-#ifndef ABR_AB_LDS_TABLES
 #include "abr_env_async.h"
-#endif
 
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
@@ -1446,11 +1413,7 @@ constexpr int64_t kSplit3MaxLanes = 65536;
 // `auto` never picks it; it stays selectable (impl 4) and parity-tested.
 constexpr int64_t kAsyncMaxLanes = 0;
 static inline bool async_eligible(const abr_env *env) {
-#ifdef ABR_AB_LDS_TABLES
-    return false;
-#else
     return !env->p.lane_speeds && env->p.video_length + 2 <= kAvailLds;
-#endif
 }
 // fused == true: step_random / step_script (n_steps decisions per launch)
 static inline int effective_impl(const abr_env *env, bool fused = false) {
@@ -1520,7 +1483,6 @@ static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, ui
                         float *rew, uint8_t *dn, int32_t *acts, hipStream_t st) {
     const int impl = effective_impl(env, true);
     const int64_t N = env->p.n_lanes;
-#ifndef ABR_AB_LDS_TABLES
     if (impl == 4) {
         for (int32_t s0 = 0; s0 < n_steps; s0 += kMaxFuse) {
             const int32_t n = n_steps - s0 < kMaxFuse ? n_steps - s0 : kMaxFuse;
@@ -1530,9 +1492,7 @@ static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, ui
                                rew ? rew + (int64_t)s0 * N : nullptr, dn ? dn + (int64_t)s0 * N : nullptr,
                                acts ? acts + (int64_t)s0 * N : nullptr, n, seed);
         }
-    } else
-#endif
-    if (is_split(impl))
+    } else if (is_split(impl))
         launch_split<MODE>(impl, env->p, script, obs, rew, dn, acts, n_steps, seed, st);
     else
         hipLaunchKernelGGL(impl ? env_advance_kernel<MODE> : env_jump_kernel<MODE>, dim3(grid64(N)), dim3(64), 0,

@@ -24,9 +24,6 @@ struct SplitMail2 {                      // P -> S, double-buffered by iteration
 };
 constexpr int kS3Valid = 0x10000, kS3Hit = 0x100, kS3Bad = 0x200, kS3Ended = 0x400, kS3Timeout = 0x800,
               kS3Reset = 0x1000, kS3Timeout2 = 0x2000;
-#ifndef ABR_SPLIT3_PRIO_P
-#define ABR_SPLIT3_PRIO_P 1
-#endif
 
 // Wave 1: the player side.  split_role_player without its service tail: the finished step goes to S.
 template <int MODE>
@@ -36,7 +33,7 @@ __device__ __forceinline__ void split3_role_player(const EnvParams &p, SplitMail
     const int64_t i = (int64_t)blockIdx.x * 64 + l;
     const bool in_range = i < p.n_lanes;
     const abrx::Tables tb = make_tables(p);
-    __builtin_amdgcn_s_setprio(ABR_SPLIT3_PRIO_P);
+    __builtin_amdgcn_s_setprio(1);     // below the download wave (2), above the service wave (0): worth 8 %
     LaneJ s;
     s.cur.j = 0; s.cur.tpos = 0; s.cur.tlen = 1; s.cur.trace = p.traces;
     int32_t episode_no = 0, b_step = 0;
@@ -278,14 +275,9 @@ __global__ __launch_bounds__(192) void env_split3_kernel(
     __shared__ SplitMail m;
     __shared__ SplitMail2 m2;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
-    ABR_STAGE_TABLES(p);
     if (threadIdx.x == 0) { m.act_lo = 0; m.act_hi = 0; }
     __syncthreads();
-#ifndef ABR_AB_NO_ACT_RING
     if (threadIdx.x < 64) split_role_download<MODE, true>(p, m, actions, actions_out, n_total, seed);
-#else
-    if (threadIdx.x < 64) split_role_download<MODE, false>(p, m, actions, actions_out, n_total, seed);
-#endif
     else if (threadIdx.x < 128) split3_role_player<MODE>(p, m, m2, n_total);
     else split3_role_service<MODE>(p, m, m2, obs_out, reward_out, done_out, actions_out, n_total, seed);
 }

@@ -34,14 +34,6 @@
 #define ABR_STAMP(n)               // cycle stamps exist only in the diagnostic build of abr_env.hip
 #endif
 
-// Where the lane functions read the two tick tables.  The product reads them through the Tables
-// pointers (global memory: L2 hits); the A/B build of abr_env.hip that stages them in LDS
-// (-DABR_AB_LDS_TABLES, profiles/r03_ab_lds_staging.txt) points these at its __shared__ arrays.
-#ifndef ABR_ITICK
-#define ABR_ITICK(t, i) ((t).interval_tick[i])
-#define ABR_AVAIL(t, i) ((t).avail_tick[i])
-#endif
-
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
@@ -103,7 +95,7 @@ ABR_HD void lanej_init_player(LaneJ &s, const Tables &t) {
     s.k = 0; s.chunk_id = 0; s.n_su = 1; s.n_rb = 0; s.n_play = 0;
     s.last_action = -1;
     s.su = true; s.be = true; s.bf = false;
-    s.avail_k = ABR_AVAIL(t, 0);
+    s.avail_k = t.avail_tick[0];
     s.pt = 0.0;                    // play_time = 0 (:115); s.sd is set by the caller
     s.pl_left = 0; s.play_id = 0; s.pt_sum = 0.0;      // play_length = 0, play_id = 0 (:113-114)
 }
@@ -297,10 +289,10 @@ ABR_HD StepLoads lanej_begin_load(const Cursor &s, const Tables &t, int32_t chun
 #pragma unroll
 #endif
     for (int i = 0; i < kCatch + 2; i++) {
-        ld.ke[i] = ABR_ITICK(t, s.j + 1 + i);
+        ld.ke[i] = t.interval_tick[s.j + 1 + i];
         ld.bw[i] = s.trace[trace_wrap(s.tpos + i, s.tlen)];
     }
-    ld.avail_next = ABR_AVAIL(t, chunk_id + 1);
+    ld.avail_next = t.avail_tick[chunk_id + 1];
     return ld;
 }
 
@@ -320,13 +312,13 @@ ABR_HD StepStart lanej_begin_select(Cursor &s, const Tables &t, const StepLoads 
     if (adv == kCatch && k >= ke[kCatch]) {
         // more than kCatch intervals behind (a long buffer_full wait): walk, then reload
         s.j += kCatch; s.tpos = trace_wrap(s.tpos + kCatch, s.tlen);
-        int32_t e = ABR_ITICK(t, s.j + 1);
+        int32_t e = t.interval_tick[s.j + 1];
         while (k >= e && e != 0x7fffffff) {       // the table ends in INT_MAX sentinels
             s.j++;
             s.tpos = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-            e = ABR_ITICK(t, s.j + 1);
+            e = t.interval_tick[s.j + 1];
         }
-        st.ke = e; st.ke_next = ABR_ITICK(t, s.j + 2);
+        st.ke = e; st.ke_next = t.interval_tick[s.j + 2];
         st.tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
         st.c = s.trace[s.tpos] * kTickDt; st.bw_next = s.trace[st.tn];
         return st;
@@ -404,7 +396,7 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
         cs.inb = adv ? 0 : cs.inb;            // new constant: the steady state is void
         tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
         bw_next = s.trace[tn];
-        ke_next = ABR_ITICK(t, s.j + 2);
+        ke_next = t.interval_tick[s.j + 2];
         int32_t n = ke - kk;
         if (n > lim - n_dl) n = lim - n_dl;
         const int32_t adds = chain_segment<STOP_GE>(cs, c, target, n, hit);       // :160-163
