@@ -44,6 +44,7 @@ constexpr double kTickDt = 0.01;   // Simulator.py:133
 #define ABR_K_DRAIN_TAIL 16
 #endif
 constexpr int kPrologue = ABR_K_PROLOGUE;   // plain additions at the start of a download (see lanej_download)
+constexpr int kPrologue2 = 24;              // ... and of the second chunk
 
 struct Tables {
     const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
@@ -379,8 +380,22 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
 #pragma unroll
 #endif
         for (int i = 0; i < kPrologue; i++) x = x + c;
-        const bool use = (ke - kk >= kPrologue) && (lim >= kPrologue) && (x < target);
+        bool use = (ke - kk >= kPrologue) && (lim >= kPrologue) && (x < target);
         if (use) { cs.x = x; n_dl = kPrologue; kk += kPrologue; }
+        // A second chunk of plain additions, kept only if the first one was and it still fits the
+        // interval and stays below the target: right after the first 16 ticks downloaded_size crosses
+        // binades every ~1, 17, 33 ticks, where a whole loop trip buys the least.  Chunked, because an
+        // all-or-nothing 32- or 64-tick prologue falls back to nothing when it does not fit (round 2:
+        // -2 % / -5 %); same box: 16 + 16 +2.7 %, 16 + 24 +3.0 %, 16 + 16 + 16 +2.3 %, 16 + 16 + 32
+        // +1.2 %, 16 + 8 + 8 +1.1 % (profiles/r03_ab_split3.txt (5)).
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int i = 0; i < kPrologue2; i++) x = x + c;
+            use = use && (ke - kk >= kPrologue2) && (lim - n_dl >= kPrologue2) && (x < target);
+            if (use) { cs.x = x; n_dl += kPrologue2; kk += kPrologue2; }
+        }
     }
     while (!hit && n_dl < lim) {
         // Interval over?  Its successor was prefetched.  Branch-free on purpose, and the

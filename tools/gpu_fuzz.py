@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config-space fuzz on the GPU box: random configurations (chunk lengths, trace intervals, ladders,
 buffer limits, start-up lengths, ragged traces with wrap-around) x random features (one speed, one
-speed per lane, a speed schedule, per-chunk ladders) x kernel implementation (role-split, one thread per
+speed per lane, a speed schedule, per-chunk ladders) x kernel implementation (role-split with three / two waves, one thread per
 lane, asynchronous pipeline -- which serves the speed features through the role-split kernels) x call form
 (V single steps, or one fused scripted rollout), every lane's
 previous_bandwidths (float64 ==), final clocks / buffer / play_time (==), play_id (==) and episode
@@ -36,8 +36,8 @@ for seed in range(n_seeds):
     off = np.array([rng.integers(0, lens[t]) for t in tid], np.int32)
     actions = rng.integers(0, B, (N, V)).astype(np.int32)
     feature = ["plain", "lane_speeds", "schedule", "vbr", "schedule+vbr"][seed % 5]
-    impl = ["split", "jump", "async"][(seed // 5) % 3]
-    fused = (seed // 15) % 2 == 1 or impl == "async"    # one abr_env_step_script call instead of V abr_env_step calls
+    impl = ["split3", "split", "jump", "async"][(seed // 5) % 4]
+    fused = (seed // 20) % 2 == 1 or impl == "async"    # one abr_env_step_script call instead of V abr_env_step calls
     speeds, br = None, None
     if "lane_speeds" in feature:
         speeds = rng.choice([0.6, 0.8, 1.0, 1.25, 1.7, 0.9173], N)
