@@ -858,9 +858,9 @@ __device__ __forceinline__ void split_role_download(
         ABR_STAMP(0);
         if (d_alive && d_step < n_total) {
             snap_j = cur.j; snap_tpos = cur.tpos;
-            // (issuing these loads one iteration ahead, before the barrier, was measured on the
-            // same box: 1.6 % SLOWER -- 450.5 vs 443.9 us per launch -- the 19 extra live
-            // registers cost more than the hidden latency; profiles/r02_ab_prefetch.txt)
+            // (issuing these loads one iteration ahead, before the barrier, was measured twice and lost
+            // both times: two-wave kernel -1.6 %, 450.5 vs 443.9 us per launch, profiles/r02_ab_prefetch.txt;
+            // three-wave kernel, which has the registers for it, -3 %, profiles/r03_ab_split3.txt (6))
             const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
             ABR_STAMP(1);
             int32_t a;
