@@ -29,7 +29,7 @@ F64_ROWS = ["global_time", "rebuffer_time", "start_up_time", "play_time", "avera
             "buffer_level", "play_length", "last_bandwidth", "chunk_id", "play_id",
             "last_bitrate", "flags", "hist_n", "hist_sum_inv", "tick", "download_time"]
 
-DONE_EPISODE, DONE_TIMEOUT, DONE_BADACT, DONE_BADARG = 1, 2, 4, 8
+DONE_EPISODE, DONE_TIMEOUT, DONE_BADACT, DONE_BADARG, DONE_INTERNAL = 1, 2, 4, 8, 16
 
 
 class EnvConfig(C.Structure):

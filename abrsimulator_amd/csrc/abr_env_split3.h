@@ -20,7 +20,7 @@
 struct SplitMail2 {                      // P -> S, double-buffered by iteration parity
     double dl[2][64], buf[2][64], lat[2][64], pt[2][64];
     int32_t meta[2][64], step[2][64], n_dl[2][64], k[2][64], nplay_o[2][64], nrb_o[2][64], nsu_o[2][64],
-        nrb_r[2][64], nsu_r[2][64], araw[2][64];
+        nrb_r[2][64], nsu_r[2][64];
 };
 constexpr int kS3Valid = 0x10000, kS3Hit = 0x100, kS3Bad = 0x200, kS3Ended = 0x400, kS3Timeout = 0x800,
               kS3Reset = 0x1000, kS3Timeout2 = 0x2000;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void split3_role_player(const EnvParams &p, SplitMail
             if ((fl & kRecValid) && m.step[pb][l] == b_step && m.k_start[pb][l] == s.k) {
                 const int32_t a = m.action[pb][l];
                 meta = kS3Valid | (a & 0xff);
-                m2.step[cb][l] = b_step; m2.araw[cb][l] = a;
+                m2.step[cb][l] = b_step;
                 if (fl & kRecBadAct) {
                     meta |= kS3Bad;
                     b_alive = false;
