@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="env_random, N=1: skip the MPC combos/s half of BASELINE.json's metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
+    ap.add_argument("--no-split-launch", action="store_true",
+                    help="N>1: keep a timed region of --steps <= --fuse decisions as ONE launch (default: two launches "
+                         "of half the decisions, so that the first all-gather overlaps the second launch)")
     ap.add_argument("--no-strong", action="store_true",
                     help="env_random: skip the strong_1048576 block (BASELINE.json configs[3]: 1 048 576 lanes "
                          "split over the ranks of this run)")
@@ -374,6 +377,11 @@ def main():
 
     if a.workload == "env_random":
         F = max(1, min(a.fuse, K))            # decisions actually fused into one launch
+        if (world > 1 or force_dist) and not a.no_gather and not a.no_split_launch and K <= a.fuse and K >= 2:
+            # more than one rank and the whole timed region would be ONE launch: its all-gather would have
+            # nothing to hide behind (the bracket closes right after it).  Two launches of K/2 decisions put
+            # the first gather under the second launch; only the second, smaller one stays exposed.
+            F = -(-K // 2)
         run, gat = make_random_runner(env, N, F, ev, a.graph and world == 1)
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"

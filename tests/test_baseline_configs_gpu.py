@@ -503,6 +503,8 @@ def test_bench_default_line_carries_both_scaling_curves_two_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_lanes"] == 8192
+    # one timed region of 20 decisions = two launches of 10, so that the first all-gather has a launch to hide behind
+    assert line["config"]["fuse"] == 10 and line["steps"] == 20
     st = line["strong_1048576"]
     assert st["scaling"] == "strong" and st["total_lanes"] == 16384 and st["lanes_per_gpu"] == 8192
     assert st["n_gpus"] == 2 and st["value"] > 0 and st["collective"].startswith("1 all_gather_into_tensor")
