@@ -1,9 +1,13 @@
 // abr_env.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/abr_env.h.
 //
 // Hot path restated from the reference (file:line into Elliotshui/ABRSimulator):
-//   K1/K2 env_jump_kernel<MODE>     Simulator.py:95-133,135-208   event-driven (default): the
+//   K1/K2 env_jump_kernel<MODE>     Simulator.py:95-133,135-208   event-driven, one thread per lane: the
 //         tick loop's float64 sequences advanced in exact closed form (abr_lane_jump.h,
-//         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout
+//         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout, 3 fused scripted rollout
+//   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
+//         service; abr_env_split3.h): what impl 3 (auto) runs up to 65 536 lanes
+//   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to 131 072 lanes
+//   K1    env_async_kernel<MODE>    ... as an asynchronous pipeline over LDS rings (abr_env_async.h): opt-in
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
 //   K3    mpc_select_kernel<H, B>   mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H
 //   K4    episode_qoe_kernel        Simulator.py:79-86
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// K1/K2, event-driven form (default): abr_lane_jump.h does the per-lane work
+// K1/K2, event-driven form, one thread per lane: abr_lane_jump.h does the per-lane work
 // ---------------------------------------------------------------------------
 using abrx::LaneJ;
 

@@ -490,7 +490,7 @@ def test_hip_graph_capture_of_step():
 def test_timeouts_are_identical_on_every_implementation():
     """Lanes that run into max_ticks (ABR_DONE_TIMEOUT; the reference would simply keep looping):
     a starved network and a tick budget barely above the live-stream minimum, so that lanes time
-    out inside a download, right after one, and while waiting.  The three implementations must
+    out inside a download, right after one, and while waiting.  The implementations must
     agree on every output and on the final float64 state, step by step and fused."""
     rng = np.random.default_rng(71)
     V, N, L = 10, 512, 4.0
