@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libabr_hip.so")
 if os.environ.get("ABR_HIP_LIB"):          # diagnostic builds of the same ABI (csrc/Makefile)
     SO_PATH = os.path.join(CSRC, os.environ["ABR_HIP_LIB"])
+ASYNC_SO = "libabr_hip_async.so"           # diagnostic: the product + the asynchronous pipeline (impl 4)
 
 ABI_VERSION = 2
 MAX_RATES = 16
@@ -96,51 +97,47 @@ SYMBOLS = [
                                          _P, _P, _P, _P, _P]),
 ]
 
-_lib = None
+_libs = {}
 
 
 class AbrError(RuntimeError):
     pass
 
 
-def build(force=False):
-    """Compile csrc/abr_env.hip for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, "abr_env.hip")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "abr_env.h")
-    deps = [src, hdr] + [os.path.join(CSRC, h) for h in
-                         ("abr_exact_jump.h", "abr_lane_jump.h", "abr_tick_tables.h", "abr_env_async.h")]
-    stale = (not os.path.exists(SO_PATH)
-             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(d) for d in deps))
-    if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "-B", "libabr_hip.so"])
-    return SO_PATH
+def build(force=False, target="libabr_hip.so"):
+    """Compile csrc/abr_env.hip for gfx950 (hipcc cross-compiles without a GPU).  The Makefile's
+    dependency list decides whether anything has to be rebuilt."""
+    subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []) + [target])
+    return os.path.join(CSRC, target)
 
 
-def lib():
-    """The loaded C-ABI library.  Raises ImportError if it is absent -- by design."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO_PATH):
+def lib(name=None):
+    """The loaded C-ABI library.  Raises ImportError if it is absent -- by design.  `name`: a
+    diagnostic build of the same ABI in csrc/ (csrc/Makefile), e.g. ASYNC_SO; default: the product."""
+    path = os.path.join(CSRC, name) if name else SO_PATH
+    L = _libs.get(path)
+    if L is None:
+        if not os.path.exists(path):
             raise ImportError(
-                f"{SO_PATH} is missing: the HIP extension has not been built. Run "
+                f"{path} is missing: the HIP extension has not been built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
                 "abrsimulator_amd/csrc`). There is deliberately no CPU fallback.")
-        L = C.CDLL(SO_PATH)
-        for name, res, args in SYMBOLS:
+        L = C.CDLL(path)
+        for sym, res, args in SYMBOLS:
             try:
-                fn = getattr(L, name)
+                fn = getattr(L, sym)
             except AttributeError as e:
-                raise ImportError(f"{SO_PATH} does not export {name}; rebuild it") from e
+                raise ImportError(f"{path} does not export {sym}; rebuild it") from e
             fn.restype, fn.argtypes = res, args
         if L.abr_abi_version() != ABI_VERSION:
-            raise ImportError(f"{SO_PATH}: ABI version {L.abr_abi_version()} != {ABI_VERSION}")
-        _lib = L
-    return _lib
+            raise ImportError(f"{path}: ABI version {L.abr_abi_version()} != {ABI_VERSION}")
+        _libs[path] = L
+    return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise AbrError(f"abr C-ABI error {rc}: {lib().abr_last_error().decode()}")
+        raise AbrError(f"abr C-ABI error {rc}: {(L or lib()).abr_last_error().decode()}")
 
 
 def ptr(t):

@@ -7,7 +7,6 @@
 //   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
 //         service; abr_env_split3.h): what impl 3 (auto) runs up to 65 536 lanes
 //   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to 131 072 lanes
-//   K1    env_async_kernel<MODE>    ... as an asynchronous pipeline over LDS rings (abr_env_async.h): opt-in
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
 //   K3    mpc_select_kernel<H, B>   mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H
 //   K4    episode_qoe_kernel        Simulator.py:79-86
@@ -33,39 +32,7 @@
 
 #include "abr_env.h"
 
-#ifdef ABR_SPLIT_STAMPS
-// diagnostic build only: cycle accumulators per code region.  Lane 0 of each wave adds the
-// cycles since that wave's previous stamp to region n, in LDS; the totals go to global memory
-// once, at the end of the kernel (ABR_STAMP_FLUSH); read with abr_debug_read_stamps.
-__device__ unsigned long long g_st_acc[32];
-__shared__ unsigned long long g_sh_st[3][33];
-#define ABR_STAMP(n)                                                                           \
-    do {                                                                                       \
-        if ((threadIdx.x & 63) == 0) {                                                         \
-            const unsigned long long t_ = (unsigned long long)__builtin_amdgcn_s_memtime();    \
-            const unsigned w_ = (threadIdx.x >> 6) % 3;                                        \
-            g_sh_st[w_][n] += t_ - g_sh_st[w_][32];                                            \
-            g_sh_st[w_][32] = t_;                                                              \
-        }                                                                                      \
-    } while (0)
-#define ABR_STAMP_INIT()                                                                       \
-    do {                                                                                       \
-        if ((threadIdx.x & 63) == 0) {                                                         \
-            for (int q_ = 0; q_ < 32; q_++) g_sh_st[(threadIdx.x >> 6) % 3][q_] = 0;           \
-            g_sh_st[(threadIdx.x >> 6) % 3][32] = (unsigned long long)__builtin_amdgcn_s_memtime(); \
-        }                                                                                      \
-    } while (0)
-#define ABR_STAMP_FLUSH()                                                                      \
-    do {                                                                                       \
-        if ((threadIdx.x & 63) == 0)                                                           \
-            for (int q_ = 0; q_ < 32; q_++)                                                    \
-                if (g_sh_st[(threadIdx.x >> 6) % 3][q_])                                       \
-                    atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]);             \
-    } while (0)
-#else
-#define ABR_STAMP_INIT()
-#define ABR_STAMP_FLUSH()
-#endif
+#include "abr_diag_stamps.h"   // cycle stamps: no-ops unless built with -DABR_SPLIT_STAMPS (libabr_hip_stamps.so)
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
@@ -141,9 +108,9 @@ struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
-    int impl;   // 3 = auto (default): see effective_impl(); 4 = asynchronous role pipeline for fused rollouts
-                // (role-split for single steps), 2 = role-split event-driven kernels, 0 = event-driven,
-                // one thread per lane, 1 = tick-by-tick kernels (cross-check)
+    int impl;   // 3 = auto (default): see effective_impl(); 5 / 2 = role-split event-driven kernels, three / two waves
+                // per 64 lanes; 0 = event-driven, one thread per lane; 1 = tick-by-tick kernels (cross-check);
+                // 4 = asynchronous role pipeline (diagnostic build only)
     int32_t *mpc_action;            // [n_lanes] scratch of abr_env_step_mpc (in the workspace)
     void *mpc_scratch;              // predictor scratch of abr_env_step_mpc (in the workspace)
     const double *pending_speeds;   // abr_env_set_lane_speeds / _speed_schedule: latched by the next full reset
@@ -788,12 +755,25 @@ struct SplitMail {
     // P -> D, double-buffered by iteration parity
     int32_t fb_step[2][64], fb_k[2][64], fb_chunk[2][64], fb_episode[2][64], fb_alive[2][64];
     int32_t any_alive[2];
-    // three-wave kernel only (abr_env_split3.h): the policy's draws for launch steps [act_lo, act_hi), made
-    // ahead by the service wave; act[step % 64][lane].  0 / 0 = nothing there (the two-wave kernel).
+    // three-wave kernel only (abr_env_split3.h): the policy's draws for launch steps [act_hi - 64, act_hi), made
+    // ahead by the service wave; act[step % 64][lane]; act_hi is published AFTER the bytes (lds_st) and read
+    // BEFORE them (lds_ld).  0 = nothing there (the two-wave kernel).
     uint8_t act[64][64];
-    int32_t act_lo, act_hi;
+    int32_t act_hi;
 };
 constexpr int kRecValid = 1, kRecHit = 2, kRecBadAct = 4;
+
+// LDS words one wave writes while another reads them inside the same iteration (no barrier in between).
+// The LDS executes one wave's DS instructions in order, so "data, then counter" on the writer and "counter,
+// then data" on the reader need no s_waitcnt; the compiler just must not move them: relaxed atomics for the
+// counter, and a compiler-only barrier between it and the data.
+__device__ __forceinline__ int32_t lds_ld(const int32_t *w) {
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(int32_t *w, int32_t v) {
+    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define ABR_LDS_ORDER() asm volatile("" ::: "memory")
 
 __device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, int64_t i) {
     p.buf[i] = s.buf; p.sumk[i] = s.sumk;
@@ -804,24 +784,6 @@ __device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, in
     if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
     if (p.lane_speeds && p.speed_rows >= 2) { p.pl_left[i] = s.pl_left; p.play_id[i] = s.play_id; p.pt_sum[i] = s.pt_sum; }
 }
-
-#ifdef ABR_SPLIT_STAMPS
-#define SPLIT_STAMP_DECL long long st_work = 0, st_wait = 0, st_iters = 0;
-#define SPLIT_STAMP_T0 const long long st0 = __builtin_amdgcn_s_memtime();
-#define SPLIT_STAMP_T1 const long long st1 = __builtin_amdgcn_s_memtime();
-#define SPLIT_STAMP_T2 st_work += st1 - st0; st_wait += __builtin_amdgcn_s_memtime() - st1; st_iters++;
-// the unused 4th row of ep_qoe_terms: [work, wait, iterations] of D (slots 0-2) and P (slots 3-5)
-#define SPLIT_STAMP_OUT(base)                                                                       \
-    if (in_range && l < 3)                                                                           \
-        p.ep_qoe_terms[3 * p.n_lanes + (int64_t)blockIdx.x * 64 + l + (base)] =                      \
-            (double)(l == 0 ? st_work : (l == 1 ? st_wait : st_iters));
-#else
-#define SPLIT_STAMP_DECL
-#define SPLIT_STAMP_T0
-#define SPLIT_STAMP_T1
-#define SPLIT_STAMP_T2
-#define SPLIT_STAMP_OUT(base)
-#endif
 
 // Wave 0 of a workgroup: the download side of its 64 lanes.  Executes exactly one workgroup
 // barrier per iteration, as split_role_player does, and leaves the loop in the same iteration.
@@ -867,12 +829,20 @@ __device__ __forceinline__ void split_role_download(
             // three-wave kernel, which has the registers for it, -3 %, profiles/r03_ab_split3.txt (6))
             const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
             ABR_STAMP(1);
-            int32_t a;
+            int32_t a = -1;
+            bool drawn = false;
             if (MODE == 1) a = actions[i];
             else if (MODE == 3) a = actions[(int64_t)d_step * p.n_lanes + i];
-            else if (ACT_RING && d_step >= m.act_lo && d_step < m.act_hi) a = m.act[d_step & 63][l];   // drawn ahead by S
-            else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
-                                            (uint32_t)d_ep, (uint32_t)p.n_rates);
+            else if (ACT_RING) {
+                // drawn ahead by S?  counter first, then the byte it vouches for
+                const int32_t hi = lds_ld(&m.act_hi);
+                ABR_LDS_ORDER();
+                drawn = d_step < hi && d_step >= hi - 64;
+                if (drawn) a = m.act[d_step & 63][l];
+            }
+            if (MODE == 2 && !drawn)
+                a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
+                                           (uint32_t)d_ep, (uint32_t)p.n_rates);
             if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;
             flags = kRecValid;
             abrx::Download d; d.dl = 0.0; d.n_dl = 0; d.hit = false;
@@ -1084,7 +1054,9 @@ __global__ __launch_bounds__(128) void env_split_kernel(
 }
 
 #include "abr_env_split3.h"
-#include "abr_env_async.h"
+#ifdef ABR_WITH_ASYNC
+#include "abr_env_async.h"      // diagnostic build only (libabr_hip_async.so): the asynchronous pipeline `auto` never picks
+#endif
 
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
@@ -1336,12 +1308,17 @@ extern "C" int abr_env_destroy(abr_env *env) {
     return ABR_OK;
 }
 
-// 3 = auto (default), 4 = asynchronous role pipeline, 2 = role-split event-driven kernels,
+// 3 = auto (default), 5 / 2 = role-split event-driven kernels (three / two waves per 64 lanes),
 // 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (impl < 0 || impl > 5)
-        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto), 4 (async) or 5 (split3)");
+        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 5 (split3)");
+#ifndef ABR_WITH_ASYNC
+    if (impl == 4)
+        return fail(ABR_E_UNSUPPORTED, "impl 4 (the asynchronous pipeline) is not part of the product library: "
+                    "it is slower than what `auto` selects; the diagnostic build libabr_hip_async.so carries it");
+#endif
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -1409,25 +1386,25 @@ constexpr int64_t kSplitMaxLanes = 131072;
 // 65 536 lanes (8.26e9 vs 7.56e9 env-steps/s; 6.86e9 vs 6.34e9 with 20 decisions per launch); at 98 304 lanes and
 // beyond its workgroups no longer fit at once and it loses to the two-wave form.  profiles/r03_ab_split3.txt
 constexpr int64_t kSplit3MaxLanes = 65536;
-// The asynchronous pipeline (abr_env_async.h) serves FUSED rollouts only (a single step has nothing to
-// run ahead of).  Measured on MI355X at 65 536 lanes, fuse 48 (profiles/r03_async_*): 714 us per launch
-// against 418 us for the role-split kernel -- its flat download loop needs 9.75 trips per decision instead
-// of 16.6, but the passes that push / restart downloads run with 21 of 64 lanes and cost more than they
-// save (3 713 vector + 2 218 scalar instructions per 64 lanes per decision against 2 526 + 757).  So
-// `auto` never picks it; it stays selectable (impl 4) and parity-tested.
-constexpr int64_t kAsyncMaxLanes = 0;
+// The asynchronous pipeline (abr_env_async.h, impl 4) lost to the role-split kernels on MI355X (714 against 418 us
+// per launch at 65 536 lanes, profiles/r03_async_*) and `auto` never picked it: the product library is built
+// without it.  `make libabr_hip_async.so` (-DABR_WITH_ASYNC) keeps it selectable for the parity tests and records.
+#ifdef ABR_WITH_ASYNC
 static inline bool async_eligible(const abr_env *env) {
     return !env->p.lane_speeds && env->p.video_length + 2 <= kAvailLds;
 }
+#endif
 // fused == true: step_random / step_script (n_steps decisions per launch)
 static inline int effective_impl(const abr_env *env, bool fused = false) {
     int impl = env->impl;
     if (impl == 3) {
-        if (fused && env->p.n_lanes <= kAsyncMaxLanes && async_eligible(env)) return 4;
         if (env->p.n_lanes <= kSplit3MaxLanes) return 5;
         return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
     }
+#ifdef ABR_WITH_ASYNC
     if (impl == 4) return (fused && async_eligible(env)) ? 4 : 2;
+#endif
+    (void)fused;
     return impl;
 }
 static inline bool is_split(int impl) { return impl == 2 || impl == 5; }
@@ -1480,14 +1457,16 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
 }
 
 // n_steps fused decisions per lane; MODE 2: built-in random policy, MODE 3: scripted actions
-// [n_steps][n_lanes].  The asynchronous pipeline takes at most kMaxFuse decisions per launch (its
-// action table lives in LDS); longer rollouts are cut into consecutive launches on the same stream.
+// [n_steps][n_lanes].
 template <int MODE>
 static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, uint64_t seed, float *obs,
                         float *rew, uint8_t *dn, int32_t *acts, hipStream_t st) {
     const int impl = effective_impl(env, true);
     const int64_t N = env->p.n_lanes;
+#ifdef ABR_WITH_ASYNC
     if (impl == 4) {
+        // the pipeline takes at most kMaxFuse decisions per launch (its action table lives in LDS); longer
+        // rollouts are cut into consecutive launches on the same stream
         for (int32_t s0 = 0; s0 < n_steps; s0 += kMaxFuse) {
             const int32_t n = n_steps - s0 < kMaxFuse ? n_steps - s0 : kMaxFuse;
             hipLaunchKernelGGL(env_async_kernel<MODE>, dim3((unsigned)((N + kAW - 1) / kAW)), dim3(3 * kAW), 0, st,
@@ -1496,7 +1475,11 @@ static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, ui
                                rew ? rew + (int64_t)s0 * N : nullptr, dn ? dn + (int64_t)s0 * N : nullptr,
                                acts ? acts + (int64_t)s0 * N : nullptr, n, seed);
         }
-    } else if (is_split(impl))
+        HIP_TRY(hipGetLastError());
+        return ABR_OK;
+    }
+#endif
+    if (is_split(impl))
         launch_split<MODE>(impl, env->p, script, obs, rew, dn, acts, n_steps, seed, st);
     else
         hipLaunchKernelGGL(impl ? env_advance_kernel<MODE> : env_jump_kernel<MODE>, dim3(grid64(N)), dim3(64), 0,

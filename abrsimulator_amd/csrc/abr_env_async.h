@@ -1,4 +1,6 @@
-// abr_env_async.h -- K1 as an asynchronous three-role pipeline (impl 4), included by abr_env.hip.
+// abr_env_async.h -- K1 as an asynchronous three-role pipeline (impl 4), included by abr_env.hip in the
+// DIAGNOSTIC build libabr_hip_async.so only (-DABR_WITH_ASYNC): measured slower than the role-split kernels, never
+// picked by `auto`, not part of the product library.  Kept as evidence and as a parity-tested alternative.
 //
 // Same lane arithmetic as every other implementation (abr_lane_jump.h / abr_exact_jump.h,
 // Simulator.py:135-208 under R1-R3) and the same workspace, bit for bit.  What changes is who
@@ -102,16 +104,7 @@ constexpr int kM2Hit = 0x100, kM2Bad = 0x200, kM2Ended = 0x400, kM2Timeout = 0x8
               kM2Timeout2 = 0x2000;
 constexpr int kPDead = 0x40000000;
 
-// LDS words another wave writes.  The LDS executes one wave's DS instructions in order, so
-// "data, then counter" on the writer and "counter, then data" on the reader need no s_waitcnt;
-// the compiler just must not move them (the asm is a compiler-only barrier).
-__device__ __forceinline__ int32_t lds_ld(const int32_t *w) {
-    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_st(int32_t *w, int32_t v) {
-    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#define ABR_LDS_ORDER() asm volatile("" ::: "memory")
+// (lds_ld / lds_st / ABR_LDS_ORDER: abr_env.hip, shared with the three-wave kernel's action ring)
 
 #ifdef ABR_ASYNC_STATS
 // diagnostic build only (libabr_hip_astats.so): per-role cycle / count accumulators, lane 0 of each

@@ -218,7 +218,9 @@ __device__ __forceinline__ void split3_role_service(
             a_next++; a_chunk++;
             if (a_chunk >= V) { a_chunk = 0; a_ep++; }
         }
-        if (l == 0) { m.act_lo = a_next > 64 ? a_next - 64 : 0; m.act_hi = a_next; }
+        // publish: the bytes first, then the counter that vouches for them (read in that order by D)
+        ABR_LDS_ORDER();
+        if (l == 0) lds_st(&m.act_hi, a_next);
     };
     int last_cb = 0;
     ABR_STAMP_INIT();
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(192) void env_split3_kernel(
     __shared__ SplitMail m;
     __shared__ SplitMail2 m2;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
-    if (threadIdx.x == 0) { m.act_lo = 0; m.act_hi = 0; }
+    if (threadIdx.x == 0) m.act_hi = 0;
     __syncthreads();
     if (threadIdx.x < 64) split_role_download<MODE, true>(p, m, actions, actions_out, n_total, seed);
     else if (threadIdx.x < 128) split3_role_player<MODE>(p, m, m2, n_total);

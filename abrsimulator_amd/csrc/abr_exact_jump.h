@@ -110,25 +110,34 @@ ABR_HD bool jump_inside(double y, double lim, bool strict) {
     return strict ? (y > lim) : (y >= lim);
 }
 
-// Slow exact search for the jump length; only reached when the reciprocal estimate
-// was off by more than one (astronomically long jumps).  Kept out of line so that
-// the hot path stays small.
-template <int STOP>
-#if defined(__HIPCC__)
-__host__ __device__ __attribute__((noinline))
+// Most additions one segment performs.  The jump-length estimate gap * v_rcp_f64(dm) carries the
+// reciprocal's relative error eps (measured on gfx950: tests/test_exact_jump_gpu.py); while the
+// true quotient is below 1 / (2 eps) the estimate is off by less than half a step, and a longer
+// one is cut to the segment's budget <= kJumpCap, which is then certainly not too long.  A run
+// of more than 2^20 equal additions inside one binade (2.9 hours of 0.01 s ticks) simply takes
+// one segment per 2^20 steps.
+constexpr int32_t kJumpCap = 1 << 20;
+
+// min(max(v, 0), hi) for hi >= 0 in one instruction
+ABR_HD int32_t clamp0(int32_t v, int32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
 #else
-inline
+    v = (v > 0) ? v : 0;
+    return (v < hi) ? v : hi;
 #endif
-int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t room) {
+}
+
+// Wave-level "does any lane need the repair path?" -- the repair (an estimate that overshot)
+// has never been observed, so the branch around it should cost a vote, not a divergent region.
+ABR_HD bool any_lane(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
+    return __builtin_expect(__any(v) != 0, 0);
+#else
+    return v;
 #endif
-    while (m > 0 && !jump_inside<STOP>(x + (double)m * d, lim, strict)) m--;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-    while (m < room && jump_inside<STOP>(x + (double)(m + 1) * d, lim, strict)) m++;
-    return m;
 }
 
 // One SEGMENT of a chain: one exact jump to the end of the binade / just before
@@ -138,13 +147,14 @@ int32_t jump_fix(double x, double d, double lim, bool strict, int32_t m, int32_t
 // predicate.  cs.inb counts the real in-binade additions just performed (only the
 // tie case needs one before it may jump); a caller that changes c resets it to 0.
 // Straight-line selects on purpose: this is the body of the GPU hot loop.
-// BIAS (tests only) is added to the jump-length estimate: a non-zero value breaks the
-// four-candidate bracket on purpose, so that the out-of-line exact search is exercised.
+// BIAS (tests only) is added to the jump-length estimate: a non-zero value spoils it on purpose,
+// so that the repair path (estimate too long) and the short-jump path (estimate too short) run.
 template <int STOP, int BIAS = 0>
-ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bool &hit_out) {
+ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in, bool &hit_out) {
 #ifdef ABR_SEGMENT_HOOK
     ABR_SEGMENT_HOOK(STOP);              // host-side analysis builds count segments per chain kind
 #endif
+    const int32_t n = (n_in < kJumpCap) ? n_in : kJumpCap;   // see kJumpCap; callers loop until their budget is spent
     double x = cs.x;
     int32_t inb = cs.inb, a = 0;
     const int e = expo(x);
@@ -180,33 +190,39 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n, bo
             gap = x - lim;
         }
         const int32_t room = can ? n : 0;
-        // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0).
+        // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0); room <= kJumpCap.
         int32_t m0 = sat_i32(gap * rcp_est(dm));
         if (BIAS != 0) m0 = (m0 < 0x7fffff00 && m0 > -0x7fffff00) ? m0 + BIAS : m0;
-        m0 = (m0 > 0) ? m0 : 0;
-        m0 = (m0 < room) ? m0 : room;
-        // Exact settlement (x + m*d is exact while it stays inside the binade).  The
-        // estimate is within one of the answer, so the answer is among bs..bs+2 with
-        // bs = m0 - 1; the four candidates bs..bs+3 also prove the bracket: candidate 0 must
-        // be inside and candidate 3 outside, else the out-of-line exact search takes over.
-        // Candidates 1..3 are formed by adding d to the previous one: identical to
-        // x + (bs+k)*d whenever the previous candidate is inside (both are then exact), and
-        // a candidate only counts if all before it are inside.
+        m0 = clamp0(m0, room);
+        // Exact settlement (x + m*d is exact while it stays inside the binade).  With the answer
+        // m* = the longest jump that stays inside, the estimate satisfies m0 - 1 <= m* (see
+        // kJumpCap), so candidate bs = m0 - 1 is inside and the answer is the last of bs, bs + 1,
+        // bs + 2 that is: candidates 1 and 2 are formed by adding d to the previous one, identical
+        // to x + (bs+k)*d whenever the previous candidate is inside (both are then exact), and a
+        // candidate only counts if all before it are inside.  A jump SHORTER than m* is always
+        // legal -- the next segment carries on -- so nothing has to bound m* from above; only
+        // "candidate 0 is inside" is load-bearing, and it is not taken on trust: ok0 checks it,
+        // and a lane whose estimate overshot walks back to the last inside candidate.  The vote
+        // keeps that path out of the way (one compare and a scalar branch per segment).
         const int32_t bs = (m0 > 0) ? m0 - 1 : 0;
         const double y0 = x + (double)bs * d;
         const double y1 = y0 + d;
         const double y2 = y1 + d;
-        const double y3 = y2 + d;
-        const bool t0 = (bs == 0) | jump_inside<STOP>(y0, lim, strict);
         const bool t1 = (bs + 1 <= room) & jump_inside<STOP>(y1, lim, strict);
         const bool t2 = (bs + 2 <= room) & jump_inside<STOP>(y2, lim, strict) & t1;
-        const bool t3 = (bs + 3 <= room) & jump_inside<STOP>(y3, lim, strict) & t2;
         int32_t m = bs + (t1 ? 1 : 0) + (t2 ? 1 : 0);
         double xj = t2 ? y2 : (t1 ? y1 : y0);
-        const bool fine = t0 & !t3;
-        if (!fine) {
-            m = jump_fix<STOP>(x, d, lim, strict, m, room);
-            xj = x + (double)m * d;
+        const bool ok0 = (bs == 0) | jump_inside<STOP>(y0, lim, strict);
+#ifdef ABR_BRACKET_HOOK
+        ABR_BRACKET_HOOK(ok0);           // host-side analysis builds count overshooting estimates
+#endif
+        if (any_lane(!ok0)) {
+            int32_t mm = ok0 ? 0 : bs;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang loop unroll(disable) vectorize(disable)
+#endif
+            while (mm > 0 && !jump_inside<STOP>(x + (double)mm * d, lim, strict)) mm--;
+            if (!ok0) { m = mm; xj = x + (double)mm * d; }
         }
         x = xj;                          // == x when !can (m == 0)
         a = m;

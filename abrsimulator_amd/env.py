@@ -50,8 +50,14 @@ class BatchedABREnv:
 
     def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
                  device="cuda", speed=1.0, auto_reset: bool = False, max_ticks: int = 0,
-                 lane_id_base: int = 0, impl: str = "auto"):
-        self.lib = _lib.lib()
+                 lane_id_base: int = 0, impl: str = "auto", library: Optional[str] = None):
+        # `library`: a diagnostic build of the same ABI in csrc/ (csrc/Makefile).  The product library holds
+        # only what `auto` can select plus the jump / split / tick cross-checks; impl="async" (the asynchronous
+        # pipeline: measured slower, kept for the parity tests and records) lives in _lib.ASYNC_SO and is
+        # loaded from there -- an ImportError if that diagnostic library has not been built.
+        if impl == "async" and library is None:
+            library = _lib.ASYNC_SO
+        self.lib = _lib.lib(library)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("BatchedABREnv runs on a ROCm device only (no CPU path exists)")
@@ -112,30 +118,30 @@ class BatchedABREnv:
             self.traces, self.trace_off, self.trace_len = pack_traces(bw, self.device)
             self.n_traces = int(self.trace_len.numel())
             nbytes = C.c_size_t()
-            _lib.check(self.lib.abr_env_workspace_bytes(C.byref(cfg), self.n_lanes, C.byref(nbytes)))
+            self._check(self.lib.abr_env_workspace_bytes(C.byref(cfg), self.n_lanes, C.byref(nbytes)))
             self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
             assert self.workspace.data_ptr() % 256 == 0
             h = C.c_void_p()
-            _lib.check(self.lib.abr_env_create(
+            self._check(self.lib.abr_env_create(
                 C.byref(cfg), _lib.ptr(self.traces), _lib.ptr(self.trace_off),
                 _lib.ptr(self.trace_len), self.n_traces, self.n_lanes, _lib.ptr(self.workspace),
                 nbytes.value, self._stream(), C.byref(h)))
         self._h = h
         if lane_id_base:
-            _lib.check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
+            self._check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
         impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4, "split3": 5}
         if impl not in impls:
             raise ValueError("impl must be 'auto' (default: the fastest at this size, see effective_impl()), "
-                             "'async' (fused rollouts on the asynchronous download/player/service pipeline), "
                              "'split' / 'split3' (role-split event-driven kernels, two / three waves per 64 lanes), "
-                             "'jump' (event-driven, one thread per lane) or 'tick'")
+                             "'jump' (event-driven, one thread per lane) or 'tick' ('async' only with "
+                             "library=_lib.ASYNC_SO, the diagnostic build that carries the asynchronous pipeline)")
         self.impl = impl
-        _lib.check(self.lib.abr_env_set_impl(self._h, impls[impl]))
+        self._check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:
-            _lib.check(self.lib.abr_env_set_speed_schedule(self._h, _lib.ptr(self.lane_speeds),
+            self._check(self.lib.abr_env_set_speed_schedule(self._h, _lib.ptr(self.lane_speeds),
                                                            int(self.lane_speeds.shape[0])))
         if self.br_table is not None:
-            _lib.check(self.lib.abr_env_set_bitrate_table(self._h, _lib.ptr(self.br_table)))
+            self._check(self.lib.abr_env_set_bitrate_table(self._h, _lib.ptr(self.br_table)))
         self.obs = torch.zeros(OBS_DIM, self.n_lanes, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(self.n_lanes, dtype=torch.float32, device=self.device)
         self.done = torch.zeros(self.n_lanes, dtype=torch.uint8, device=self.device)
@@ -143,6 +149,9 @@ class BatchedABREnv:
         self.start_offset = None
 
     # -- plumbing ----------------------------------------------------------
+    def _check(self, rc):
+        _lib.check(rc, self.lib)
+
     def _stream(self):
         return _lib.current_stream(self.device)
 
@@ -150,10 +159,10 @@ class BatchedABREnv:
         """One C-ABI call with self.device current: the library launches on the stream it is
         handed, and HIP launches go to the CURRENT device."""
         if torch.cuda.current_device() == self._dev_index:     # the common case: no context switch to pay
-            _lib.check(fn(*args, self._stream()))
+            self._check(fn(*args, self._stream()))
         else:
             with torch.cuda.device(self.device):
-                _lib.check(fn(*args, self._stream()))
+                self._check(fn(*args, self._stream()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -257,7 +266,7 @@ class BatchedABREnv:
         """Name of the kernels the handle resolves to right now ('auto' is a policy, not a kernel):
         fused=True for step_random / step_script, False for step."""
         v = C.c_int32()
-        _lib.check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
+        self._check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
         return {0: "jump", 1: "tick", 2: "split", 4: "async", 5: "split3"}[v.value]
 
     def step_mpc(self, controller, n_steps: int, out=None, want_obs=True, want_actions=True):
@@ -297,7 +306,7 @@ class BatchedABREnv:
 
     def state_view(self):
         v = _lib.StateView()
-        _lib.check(self.lib.abr_env_get_state(self._h, C.byref(v)))
+        self._check(self.lib.abr_env_get_state(self._h, C.byref(v)))
         return v
 
     def _view(self, addr, dtype, shape):
@@ -337,7 +346,7 @@ class BatchedABREnv:
         self.trace_id, self.start_offset = sd["trace_id"], sd["start_offset"]
         # the handle now carries episodes in flight (a freshly built one had none): the speeds /
         # bitrate table given to __init__ are in force, later setter calls are latched again
-        _lib.check(self.lib.abr_env_notify_restore(self._h))
+        self._check(self.lib.abr_env_notify_restore(self._h))
 
 
 def obs_dict(obs):

@@ -37,10 +37,13 @@
 extern "C" {
 #endif
 
-/* 2: abr_env_step_script, abr_env_get_effective_impl, impl 4 (asynchronous pipeline); since 1 also:
- * workspace layout grew, abr_env_set_lane_speeds / _speed_schedule / _bitrate_table are latched
- * until the next full reset, every re-reset advances the policy's episode counter, default impl
- * is 3 (auto).  A host built against version 1 must be rebuilt. */
+/* 2: abr_env_step_script, abr_env_get_effective_impl, abr_env_notify_restore, impl 5 (three waves per 64
+ * lanes); struct abr_mpc_options GREW (mask_is_done + reserved_ appended: a version-1 host passes a
+ * shorter struct and must be rebuilt); since 1 also: workspace layout grew, abr_env_set_lane_speeds /
+ * _speed_schedule / _bitrate_table are latched until the next full reset, every re-reset advances the
+ * policy's episode counter, default impl is 3 (auto).  A host built against version 1 must be rebuilt.
+ * (impl 4, the asynchronous pipeline of round 3, is no longer part of the product library: it lost to
+ * what `auto` selects; csrc/Makefile: libabr_hip_async.so is a diagnostic build that still carries it.) */
 #define ABR_ABI_VERSION 2
 #define ABR_MAX_RATES 16
 #define ABR_MAX_HORIZON 8
@@ -59,8 +62,8 @@ extern "C" {
 #define ABR_DONE_BADARG 0x8     /* abr_env_reset got a trace id outside [0, n_traces) or a negative start
                                    offset for this lane: lane frozen, nothing read out of bounds */
 
-#define ABR_DONE_INTERNAL 0x10  /* the asynchronous pipeline's watchdog fired (a bug in this library, never a
-                                   property of the inputs): the lane is frozen, its later records are void */
+#define ABR_DONE_INTERNAL 0x10  /* RESERVED: never set by the product library (the diagnostic asynchronous
+                                   pipeline uses it for its watchdog) */
 
 /* float32 observation rows written by reset/step: the four arguments of
  * get_next_bitrate (Simulator.py:155) first, then run() locals at that instant */
@@ -169,17 +172,15 @@ int abr_env_notify_restore(abr_env *env);
 /* Which kernels serve reset/step: 2 = event-driven (exact closed-form stepping of the
  * float64 tick sequences) with each lane's download side and player side on two waves of one
  * workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per 0.01 s tick;
- * 4 = fused rollouts (abr_env_step_random / abr_env_step_script) on the asynchronous
- * download / player / service pipeline, single steps as 2 (it needs one play speed for all lanes
- * and video_length <= 1022, else it serves as 2);
  * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
  * time, history, reward, observation, episode end);
  * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 131 072 lanes,
- * 0 above (4 is slower than 2 at every size measured so far and is never picked).  All produce identical state and outputs (the
- * workspace is interchangeable between them); 1 exists as an independent cross-check. */
+ * 0 above.  All produce identical state and outputs (the workspace is interchangeable between
+ * them); 1 exists as an independent cross-check.  4 (the asynchronous pipeline) is answered with
+ * ABR_E_UNSUPPORTED by the product library. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 
-/* The implementation (0, 1, 2 or 4) the handle resolves to right now: fused != 0 for
+/* The implementation (0, 1, 2 or 5; never 3) the handle resolves to right now: fused != 0 for
  * abr_env_step_random / abr_env_step_script, 0 for abr_env_step. */
 int abr_env_get_effective_impl(abr_env *env, int32_t fused, int32_t *impl_out);
 

@@ -168,3 +168,17 @@ def test_env_refuses_cpu_device(L):
     mpd = A.MPD(4, 4, 20, 8, A.Chunk([1.0, 2.0]))
     with pytest.raises(ValueError):
         A.BatchedABREnv(mpd, A.QOEMetric(1, 1, 1, 1), A.NetworkInfo(1.0, [1.0, 2.0]), 8, device="cpu")
+
+
+def test_product_library_ships_only_selectable_kernels(L):
+    """The product code object holds what `auto` can select plus the explicit cross-checks; the rejected
+    asynchronous pipeline and the cycle-stamp instrumentation live in diagnostic builds only
+    (csrc/Makefile), the out-of-line jump search is gone, and impl 4 is refused by the product."""
+    blob = open(L.SO_PATH, "rb").read()
+    assert b"env_split3_kernel" in blob and b"env_split_kernel" in blob and b"env_jump_kernel" in blob
+    for sym in (b"env_async_kernel", b"g_st_acc", b"g_async_stats", b"jump_fix", b"abr_debug_read_stamps"):
+        assert sym not in blob, sym
+    src = os.path.join(ROOT, "abrsimulator_amd", "csrc")
+    hot = open(os.path.join(src, "abr_env.hip")).read()
+    assert "#ifdef ABR_WITH_ASYNC\n#include \"abr_env_async.h\"" in hot
+    assert "noinline" not in open(os.path.join(src, "abr_exact_jump.h")).read()

@@ -12,7 +12,8 @@ import pytest
 import torch
 
 from conftest import ENV_GOLDENS, load_golden
-from helpers import F64_EXACT, make_env, philox_action
+from helpers import (F64_EXACT, auto_reset_rollout_rewards, golden_rewards, make_env, oracle_rewards,
+                     philox_action)
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +46,8 @@ def test_scripted_rollout_matches_reference_goldens(name, impl):
         assert np.array_equal(obs[s, 1], g["arg_last_bitrate"][:, s + 1].astype(np.float32)), (name, s)
     done = out["done"].cpu().numpy()
     assert (done[:-1] == 0).all() and (done[-1] == 1).all()
+    # every per-step reward == float32 of the value derived from the reference's frames
+    assert np.array_equal(out["reward"].cpu().numpy().T, golden_rewards(m, g)), (name, impl)
     qoe = env.episode_qoe().cpu().numpy()
     assert np.allclose(qoe, g["final_qoe"], rtol=1e-10), (qoe[:4], g["final_qoe"][:4])
     lat = float(m["weights"][3])
@@ -74,10 +77,12 @@ def test_scripted_rollout_random_configurations_against_oracle(oracle, seed):
                          meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, max_ticks=4_000_000)
     ref = None
-    for impl in ("async", "jump"):
+    want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"])
+    for impl in ("async", "split3", "jump"):
         env = make_env(meta, traces, N, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
         env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
         out = env.step_script(torch.from_numpy(actions.T.copy()))
+        assert np.array_equal(out["reward"].cpu().numpy().T, want_rew), (impl, seed)
         obs = out["obs"].cpu().numpy()
         for s in range(V - 1):
             for row, want in _obs_expect(steps, s + 1).items():
@@ -103,7 +108,12 @@ BENCH_META = dict(ladder=[0.3, 0.75, 1.2, 1.85, 2.85, 4.3], chunk_length=4.0, vi
                   start_up_length=8.0, interval=1.0, weights=[4.3, 1, 1, 0.1], speed=1.0)
 
 
-def test_fused_random_rollout_identical_to_other_implementations():
+def _bench_cfg(oracle, meta):
+    return oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                          meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
+
+
+def test_fused_random_rollout_identical_to_other_implementations(oracle):
     """The bench shape (auto_reset, 48-chunk episodes, ragged traces), a lane count that is not a
     multiple of the 256-lane workgroup, 103 decisions = two launches (64 + 39) inside one call; then
     the same rollout cut into uneven calls (state handed over between launches)."""
@@ -127,6 +137,11 @@ def test_fused_random_rollout_identical_to_other_implementations():
         for q in (1, 2, 3):
             assert torch.equal(states[impl][q], states["async"][q]), (impl, q)
     assert int((outs["async"]["done"] == 1).sum()) >= 2 * N - N // 2      # episodes really ended and re-armed
+    # ... and the rewards are the reference-derived ones, element by element, across two auto-resets
+    want = auto_reset_rollout_rewards(oracle, _bench_cfg(oracle, BENCH_META), traces, tid, off,
+                                      outs["async"]["actions"].cpu().numpy(), BENCH_META["weights"],
+                                      ladder=BENCH_META["ladder"])
+    assert np.array_equal(outs["async"]["reward"].cpu().numpy(), want)
     # uneven cuts, alternating implementations between calls: the workspace is interchangeable
     env = make_env(BENCH_META, traces, N, impl="async", auto_reset=True, lane_id_base=12345)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
@@ -139,7 +154,7 @@ def test_fused_random_rollout_identical_to_other_implementations():
         assert torch.equal(torch.cat([p[k] for p in parts]), outs["async"][k]), k
 
 
-def test_buffer_full_gating_redoes_downloads():
+def test_buffer_full_gating_redoes_downloads(oracle):
     """A buffer limit of 1.5 chunks and a fast network: buffer_full gates almost every download
     (Simulator.py:144), so the download role's "not gated" guess is wrong all the time and the
     player sends it back to the snapshot with the true call-site tick.  Results must not change."""
@@ -159,6 +174,9 @@ def test_buffer_full_gating_redoes_downloads():
             assert torch.equal(outs[impl][0][k], outs["async"][0][k]), (impl, k)
         for k in outs["async"][1]:
             assert torch.equal(outs[impl][1][k], outs["async"][1][k]), (impl, k)
+    want = auto_reset_rollout_rewards(oracle, _bench_cfg(oracle, meta), traces, tid, off,
+                                      outs["async"][0]["actions"].cpu().numpy(), meta["weights"], ladder=meta["ladder"])
+    assert np.array_equal(outs["async"][0]["reward"].cpu().numpy(), want)
     # the gating really happened: buffer_full set at many call sites' predecessors means waits beyond availability
     fl = outs["async"][1]["buffer_level"]
     assert float(fl.max()) <= 6.0 + 4.0

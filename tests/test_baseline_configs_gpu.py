@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from conftest import ROOT
-from helpers import make_env, philox_action
+from helpers import make_env, oracle_rewards, philox_action
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +110,9 @@ def test_shard_shape_131072_lanes_equals_unsharded_slice_and_oracle(oracle):
             assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), s
             assert np.array_equal(o[s, 4], steps["global_time"][:, s + 1].astype(np.float32)), s
             assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32)), s
+        # every reward element of the sampled lanes == float32 of the oracle-derived value
+        assert np.array_equal(out["reward"].cpu().numpy()[:, pick].T,
+                              oracle_rewards(steps, fin, acts, WEIGHTS, ladder=LADDER))
         # the finished episode (auto_reset keeps its record): float64 QoE against the oracle
         assert np.allclose(sh.episode_qoe().cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
 
@@ -141,6 +144,7 @@ def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr, path):
         # abr_env_step_mpc: select -> step for all V decisions on the device
         out = env.step_mpc(ctl, V)
         gpu_actions = out["actions"].cpu().numpy().T
+        gpu_rewards = list(out["reward"].cpu().numpy())
         d = out["done"].cpu().numpy()
         assert (d[:-1] == 0).all() and (d[-1] == 1).all()
         # a second call on the finished lanes takes no decision and changes nothing
@@ -149,16 +153,18 @@ def test_mpc_rollout_on_ragged_traces_against_oracle(oracle, wv, wr, path):
         assert (again["actions"].cpu().numpy() == -1).all() and (again["done"].cpu().numpy() == 1).all()
         assert torch.equal(env.observe_f64()["global_time"], before)
     else:
-        gpu_actions = []
+        gpu_actions, gpu_rewards = [], []
         for s in range(V):
             a = torch.clamp(ctl.next_bitrate(), min=0)      # D13 at chunk 0: "no decision" -> rate 0
             gpu_actions.append(a.cpu().numpy().copy())
-            env.step(a)
+            gpu_rewards.append(env.step(a)[1].cpu().numpy().copy())
         gpu_actions = np.stack(gpu_actions, 1)
     ecfg = oracle.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0)
     mcfg = oracle.mpc_cfg(6, H, V, L, MAX_BUFFER, wv, wr, 0.0)
     steps, bw, acts, fin = oracle.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid, off, threads=8)
     assert np.array_equal(gpu_actions, acts)
+    # the environment downloads from the single ladder, so the reward's variance term uses it (:82)
+    assert np.array_equal(np.stack(gpu_rewards, 1), oracle_rewards(steps, fin, acts, WEIGHTS, ladder=LADDER))
     if wr < 1.0:
         assert len(np.unique(acts)) == 6                     # every rate is exercised
     # some lanes wrapped around their trace (the reference would raise IndexError, D7)
@@ -184,6 +190,9 @@ def _rollout_vs_oracle(oracle, env, ctl, traces, tid, off, br, sz, wv, wr, pick,
     mcfg = oracle.mpc_cfg(6, H, V, L, MAX_BUFFER, wv, wr, 0.0)
     steps, bw, acts, fin = oracle.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid[pick], off[pick], threads=16)
     assert np.array_equal(a_all[:, pick].T, acts)
+    # every reward element of the sampled lanes == float32 of the oracle-derived value (the environment
+    # downloads from its single ladder, so that is what the variance term reads)
+    assert np.array_equal(out["reward"].cpu().numpy()[:, pick].T, oracle_rewards(steps, fin, acts, WEIGHTS, ladder=LADDER))
     assert np.array_equal(env.history()[1].cpu().numpy()[:, pick].T, bw)
     assert np.allclose(env.episode_qoe().cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
     f = env.observe_f64()
@@ -384,7 +393,7 @@ def test_mpc_previous_bitrate_outside_the_ladder_is_no_decision():
 # ---------------------------------------------------------------------------------------------
 # per-chunk ladders (8f rank 2, build-defined: the reference cannot run a list-MPD)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("impl", ["split", "jump", "tick"])
+@pytest.mark.parametrize("impl", ["split3", "split", "jump", "tick"])
 def test_per_chunk_ladders_against_oracle(oracle, impl, tmp_path):
     import abrsimulator_amd as A
     rng = np.random.default_rng(66)
@@ -404,11 +413,15 @@ def test_per_chunk_ladders_against_oracle(oracle, impl, tmp_path):
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, actions)
     acts = torch.from_numpy(actions).cuda()
     rew = np.zeros(N)
+    # the variance term reads chunk s's OWN ladder row for a_s and chunk s-1's for a_(s-1)
+    want_rew = oracle_rewards(steps, fin, actions, WEIGHTS, br_table=br)
+    assert not np.array_equal(want_rew, oracle_rewards(steps, fin, actions, WEIGHTS, ladder=list(br[0])))
     for s in range(VV):
         f = env.observe_f64()
         for k in ("global_time", "buffer_level", "rebuffer_time", "start_up_time", "play_time"):
             assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (s, k)
         _, r, _ = env.step(acts[:, s].contiguous())
+        assert np.array_equal(r.cpu().numpy(), want_rew[:, s]), (impl, s)
         rew += r.double().cpu().numpy()
     assert np.array_equal(env.history()[1].cpu().numpy().T, bw)
     q = env.episode_qoe().cpu().numpy()
@@ -442,6 +455,9 @@ def test_fused_random_rollout_with_per_chunk_ladders(oracle):
         for s in range(VV - 1):
             assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), (ep, s)
             assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32)), (ep, s)
+        # rewards of the default (three-wave) fused kernel on per-chunk ladders, across the auto-reset
+        assert np.array_equal(out["reward"].cpu().numpy()[ep * VV:(ep + 1) * VV].T,
+                              oracle_rewards(steps, fin, a, WEIGHTS, br_table=br)), ep
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
 
 

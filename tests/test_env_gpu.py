@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import ENV_GOLDENS, load_golden
-from helpers import F64_EXACT, make_env, philox_action
+from helpers import F64_EXACT, golden_rewards, make_env, oracle_rewards, philox_action
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,7 @@ def test_step_matches_reference_goldens(name, impl):
     obs = env.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
     acts = torch.from_numpy(g["actions"]).cuda()
     rew_sum = np.zeros(N)
+    want_rew = golden_rewards(m, g)                # float32 of the reference-derived value, [N, V]
     for s in range(V):
         _cmp_step(env.observe_f64(), g, s, name)
         o = obs.cpu().numpy()
@@ -57,6 +58,8 @@ def test_step_matches_reference_goldens(name, impl):
         assert np.array_equal(o[2], g["arg_last_bandwidth"][:, s].astype(np.float32))
         assert np.array_equal(o[0], g["chunk_id"][:, s].astype(np.float32))
         obs, rew, done = env.step(acts[:, s].contiguous())
+        # the per-step linear QoE reward, element by element (Simulator.py:79-86 split at :155)
+        assert np.array_equal(rew.cpu().numpy(), want_rew[:, s]), (name, impl, s, rew[:4], want_rew[:4, s])
         rew_sum += rew.double().cpu().numpy()
         d = done.cpu().numpy()
         assert (d == (1 if s == V - 1 else 0)).all(), (s, d)
@@ -112,6 +115,7 @@ def test_step_matches_oracle_seeded(oracle, case, impl):
     env = make_env(meta, traces, N, impl=impl)
     env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
     acts = torch.from_numpy(actions).cuda()
+    want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"])
     for s in range(V):
         f = env.observe_f64()
         for k in F64_EXACT:
@@ -119,7 +123,8 @@ def test_step_matches_oracle_seeded(oracle, case, impl):
         assert np.allclose(f["average_latency"].cpu().numpy(), steps["average_latency"][:, s],
                            rtol=LAT_RTOL, atol=1e-12)
         assert np.array_equal(f["last_bandwidth"].cpu().numpy(), steps["last_bandwidth"][:, s])
-        env.step(acts[:, s].contiguous())
+        _, rew, _ = env.step(acts[:, s].contiguous())
+        assert np.array_equal(rew.cpu().numpy(), want_rew[:, s]), (impl, s)
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
     assert np.array_equal(env.observe_f64()["global_time"].cpu().numpy(), fin["global_time"])
 
@@ -145,6 +150,8 @@ def test_step_random_fused_equals_stepwise_and_oracle(oracle):
         assert np.array_equal(obs[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32))
     assert (out["done"].cpu().numpy()[:-1] == 0).all() and (out["done"].cpu().numpy()[-1] == 1).all()
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
+    assert np.array_equal(out["reward"].cpu().numpy().T,
+                          oracle_rewards(steps, fin, acts.T, meta["weights"], ladder=meta["ladder"]))
     # step-by-step twin, on the OTHER implementation
     env2 = make_env(meta, traces, N, impl="tick")
     env2.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
@@ -173,6 +180,17 @@ def test_auto_reset_and_lane_id_base(oracle):
                          meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, want1.T.copy())
     obs = out["obs"].cpu().numpy()
+    # rewards element by element ACROSS the episode boundary: the terminal step of episode 0 closes on
+    # that episode's final timers, the first step of episode 1 starts its deltas from 0 again, and the
+    # variance term does not reach back into the finished episode
+    rew = out["reward"].cpu().numpy()
+    steps0, _, fin0, _ = oracle.env_batch(cfg, traces, trace_id, offset, acts[:V].T.copy())
+    assert np.array_equal(rew[:V].T, oracle_rewards(steps0, fin0, acts[:V].T, meta["weights"], ladder=meta["ladder"]))
+    assert np.array_equal(rew[V:2 * V].T, oracle_rewards(steps, fin, want1.T, meta["weights"], ladder=meta["ladder"]))
+    want2 = np.stack([philox_action(seed, np.arange(N), s, 2, 6) for s in range(V)])
+    steps2, _, fin2, _ = oracle.env_batch(cfg, traces, trace_id, offset, want2.T.copy())
+    assert np.array_equal(rew[2 * V:].T, oracle_rewards(steps2, fin2, want2.T, meta["weights"],
+                                                        ladder=meta["ladder"])[:, :2])
     # obs returned with done is the new episode's first call site
     assert np.array_equal(obs[V - 1, 4], steps["global_time"][:, 0].astype(np.float32))
     assert np.array_equal(obs[V, 3], steps["buffer_level"][:, 1].astype(np.float32))
@@ -260,6 +278,9 @@ def test_full_size_properties(oracle):
         assert np.array_equal(o[s, 4], steps["global_time"][:, s + 1].astype(np.float32))
         assert np.array_equal(o[s, 2], steps["last_bandwidth"][:, s + 1].astype(np.float32))
         assert np.array_equal(o[s, 6], steps["rebuffer_time"][:, s + 1].astype(np.float32))
+    # every reward element of the sampled lanes == float32 of the oracle-derived value
+    assert np.array_equal(out["reward"].cpu().numpy()[:, pick].T,
+                          oracle_rewards(steps, fin, acts, meta["weights"], ladder=meta["ladder"]))
     ah, bh = env.history()
     assert np.array_equal(bh.cpu().numpy()[:, pick].T, bw)          # float64 throughputs, bit-exact
     assert np.allclose(q.cpu().numpy()[pick], fin["qoe"], rtol=1e-10)
@@ -314,6 +335,7 @@ def test_per_lane_speeds(oracle):
     cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
                          meta["start_up_length"], meta["interval"], meta["weights"], 1.0)
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, speeds=speeds)
+    want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"])
     env = make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N)
     obs = env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
     acts = torch.from_numpy(actions).cuda()
@@ -325,7 +347,8 @@ def test_per_lane_speeds(oracle):
         assert np.allclose(f["average_latency"].cpu().numpy(), steps["average_latency"][:, s],
                            rtol=LAT_RTOL, atol=1e-12)
         assert np.array_equal(obs.cpu().numpy()[5], steps["play_time"][:, s].astype(np.float32))
-        obs, _, _ = env.step(acts[:, s].contiguous())
+        obs, rew, _ = env.step(acts[:, s].contiguous())
+        assert np.array_equal(rew.cpu().numpy(), want_rew[:, s]), s
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
     assert np.array_equal(env.observe_f64()["play_time"].cpu().numpy(), fin["play_time"])
     # the tick-by-tick kernels take one speed only
@@ -334,7 +357,7 @@ def test_per_lane_speeds(oracle):
         make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N, impl="tick")
 
 
-@pytest.mark.parametrize("impl", ["split", "jump"])
+@pytest.mark.parametrize("impl", ["split3", "split", "jump"])
 def test_speed_schedule_matches_reference_golden(impl):
     """8f rank 3, second half: the play speed is re-read at every played chunk
     (Simulator.py:176-177).  The fixture is the reference driven by a scripted speed
@@ -345,10 +368,17 @@ def test_speed_schedule_matches_reference_golden(impl):
     env = make_env(dict(m, speed=sched), g["traces"], N, impl=impl)
     obs = env.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
     acts = torch.from_numpy(g["actions"]).cuda()
+    want_rew = golden_rewards(m, g)
     for s in range(V):
         _cmp_step(env.observe_f64(), g, s, "env_speed_schedule")
         assert np.array_equal(obs.cpu().numpy()[5], g["play_time"][:, s].astype(np.float32))
-        obs, _, _ = env.step(acts[:, s].contiguous())
+        obs, rew, _ = env.step(acts[:, s].contiguous())
+        assert np.array_equal(rew.cpu().numpy(), want_rew[:, s]), (impl, s)
+    # ... and the same episode in ONE fused scripted call
+    env2 = make_env(dict(m, speed=sched), g["traces"], N, impl=impl)
+    env2.reset(torch.from_numpy(g["trace_id"]), torch.from_numpy(g["offset"]))
+    out2 = env2.step_script(torch.from_numpy(g["actions"].T.copy()))
+    assert np.array_equal(out2["reward"].cpu().numpy().T, want_rew), impl
     f = env.observe_f64()
     for k in ["global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"]:
         assert np.array_equal(f[k].cpu().numpy(), g["final_" + k]), k
@@ -378,6 +408,8 @@ def test_speed_schedule_fused_and_simulator_class(oracle):
         for s in range(V - 1):
             assert np.array_equal(o[s, 3], steps["buffer_level"][:, s + 1].astype(np.float32)), (ep, s)
             assert np.array_equal(o[s, 5], steps["play_time"][:, s + 1].astype(np.float32)), (ep, s)
+        assert np.array_equal(out["reward"].cpu().numpy()[ep * V:(ep + 1) * V].T,
+                              oracle_rewards(steps, fin, a, meta["weights"], ladder=meta["ladder"])), ep
     assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10)
 
     class Replay:
@@ -421,6 +453,7 @@ def test_random_configurations_against_oracle(oracle, seed):
     cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"],
                          meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, max_ticks=4_000_000)
+    want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"])
     for impl in IMPLS:
         env = make_env(meta, traces, N, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
         env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
@@ -429,7 +462,8 @@ def test_random_configurations_against_oracle(oracle, seed):
             f = env.observe_f64()
             for k in F64_EXACT:
                 assert np.array_equal(f[k].cpu().numpy(), steps[k][:, s]), (impl, s, k)
-            env.step(acts[:, s].contiguous())
+            _, rew, _ = env.step(acts[:, s].contiguous())
+            assert np.array_equal(rew.cpu().numpy(), want_rew[:, s]), (impl, s)
         assert np.array_equal(env.history()[1].cpu().numpy().T, bw), impl
         assert np.allclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10), impl
 

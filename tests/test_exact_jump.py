@@ -23,7 +23,7 @@ def H():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-fno-fast-math", "-I", inc, SRC, "-o", SO])
     lib = C.CDLL(SO)
-    for f in (lib.fuzz_ge, lib.fuzz_le, lib.fuzz_lt):
+    for f in (lib.fuzz_ge, lib.fuzz_le, lib.fuzz_lt, lib.fuzz_biased, lib.overshoot_count):
         f.restype = C.c_int64
     return lib
 
@@ -140,3 +140,48 @@ def test_landing_exactly_on_a_power_of_two(H):
         x = y * 0.75; x1 = x + c; x2 = x1 + c; d = x2 - x1
         xs2.append(y - 3 * d)
     _run(H.fuzz_ge, np.array(xs2), cs, np.full(len(xs), 1e9), ns)
+
+
+def _run_biased(H, kind, bias, x0, c, thr, n):
+    import functools
+    fn = functools.partial(H.fuzz_biased, C.c_int32(kind), C.c_int32(bias))
+    return _run(fn, x0, c, thr, n)
+
+
+def test_spoiled_estimates_are_repaired_and_good_ones_never_overshoot(H):
+    """The settlement of a segment trusts the jump-length estimate for speed only.  With the estimate
+    spoiled by +4 (candidate 0 lands outside: the repair walks back) or -4 (the jump is shorter than it
+    could be: the next segment carries on) the chain is still the naive loop bit for bit; and on
+    unspoiled inputs -- ties, exact thresholds, power-of-two landings, long jumps -- the repair path is
+    never entered (the counter the harness keeps stays 0), which is what makes it free."""
+    rng = np.random.default_rng(6)
+    N = 120_000
+    c = rng.uniform(0.05, 12.0, N).astype(np.float32).astype(np.float64) * 0.01
+    x0 = np.where(rng.random(N) < 0.4, 0.0, rng.uniform(0, 20, N))
+    thr = rng.choice([0.3, 0.75, 1.2, 1.85, 2.85, 4.3], N) * rng.choice([1.0, 2.0, 4.0], N)
+    n = rng.integers(1, 3000, N)
+    xb = np.where(rng.random(N) < 0.5, rng.integers(1, 7, N) * 4.0, rng.uniform(0.001, 30, N))
+    sd = rng.choice([0.01, 0.0125, 0.005, 0.02], N)
+    t2 = rng.choice([20.0, 3.0, 5.0, 9.0], N)
+    e = rng.integers(-8, 6, N)
+    base = np.ldexp(1.0, e)
+    u = base * 2.0 ** -52
+    xt = base * (1.0 + rng.integers(0, 1 << 20, N) * 2.0 ** -52)
+    ct = rng.integers(1, 1 << 44, N).astype(np.float64) * u + u / 2           # ties
+    thr_t = xt + ct * rng.integers(1, 600, N)
+    H.overshoot_count(1)
+    _run(H.fuzz_ge, x0, c, thr, n)
+    _run(H.fuzz_le, xb, -sd, np.zeros(N), rng.integers(1, 4000, N))
+    _run(H.fuzz_lt, t2 + rng.uniform(0, 5, N), -sd, t2, rng.integers(1, 4000, N))
+    _run(H.fuzz_ge, xt, ct, thr_t, rng.integers(1, 500, N))
+    # jumps of millions of steps inside one binade (cut at kJumpCap per segment)
+    _run(H.fuzz_ge, [1.0, 1.0, 1.5, 1024.0], [2.0 ** -30, 2.0 ** -29 + 2.0 ** -52, 3 * 2.0 ** -31, 2.0 ** -17],
+         [10.0, 1.2, 1.9, 1e9], np.array([1 << 23, (1 << 23) + 12345, 1 << 22, 1 << 23], np.int32))
+    assert H.overshoot_count(1) == 0
+    for bias in (4, -4):
+        _run_biased(H, 0, bias, x0, c, thr, n)
+        _run_biased(H, 1, bias, xb, -sd, np.zeros(N), rng.integers(1, 4000, N))
+        _run_biased(H, 2, bias, t2 + rng.uniform(0, 5, N), -sd, t2, rng.integers(1, 4000, N))
+        _run_biased(H, 0, bias, xt, ct, thr_t, rng.integers(1, 500, N))
+        over = H.overshoot_count(1)
+        assert (over > 1000) if bias > 0 else (over == 0), (bias, over)

@@ -151,3 +151,21 @@ def test_pure_python_restatement_bit_exact(name):
                 assert o[k] == g[k][i, s], (i, s, k)
             assert o["last_bandwidth"] == g["arg_last_bandwidth"][i, s]
         assert env.t == g["final_global_time"][i]
+
+
+@pytest.mark.parametrize("name", ENV_GOLDENS + ["env_speed_schedule"])
+def test_reward_split_of_the_goldens_adds_up_to_the_references_qoe(name):
+    """tests/helpers.py: golden_rewards() is the expected value of every per-step reward the GPU tests
+    compare element by element.  Pin the derivation itself to the reference: in float64 the split of
+    calculate_qoe (Simulator.py:79-86) at the call sites plus the latency term IS run()'s return value."""
+    from helpers import golden_rewards
+    m, g = load_golden(name)
+    r = golden_rewards(m, g, dtype=np.float64)
+    assert r.shape == g["actions"].shape
+    total = r.sum(1) + m["weights"][3] * g["final_average_latency"]
+    assert np.allclose(total, g["final_qoe"], rtol=1e-12, atol=1e-12), np.abs(total - g["final_qoe"]).max()
+    # the variance term alone, as calculate_qoe forms it (:81-82)
+    lad = np.asarray(m["ladder"])
+    var = np.abs(np.diff(lad[g["actions"]], axis=1)).sum(1)
+    rest = m["weights"][0] * g["final_rebuffer_time"] + m["weights"][2] * g["final_start_up_time"]
+    assert np.allclose(r.sum(1), rest + m["weights"][1] * var, rtol=1e-12, atol=1e-12)
