@@ -172,7 +172,7 @@ __device__ __forceinline__ void async_role_download(const EnvParams &p, AsyncSha
     for (int q = 0; q < kStage; q++) stg[q] = 0.0;
     // the download in flight
     double c = 0.0, bwn = 0.0, x = 0.0, target = 0.0;
-    int32_t ke = 0, ken = 0, tn = 0, inb = 0, n_dl = 0, kk = 0, lim = 0, k_start = 0, act = 0;
+    int32_t ke = 0, ken = 0, tn = 0, inb = -1 /* ChainState::eb */, n_dl = 0, kk = 0, lim = 0, k_start = 0, act = 0;
     int32_t snap_j = 0, snap_tpos = 0;
     bool hit = false, bad = false, bwn_ok = false, snapped = false, resume = false, blocked = false;
     int32_t head = 0, epoch = 0, since_pass = 0, spins = 0;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void async_role_download(const EnvParams &p, AsyncSha
                     ke = adv ? ken : ke;
                     j += adv ? 1 : 0;
                     tpos = adv ? tn : tpos;
-                    inb = adv ? 0 : inb;
+                    inb = adv ? -1 : inb;
                     tn = (tpos + 1 == tlen) ? 0 : tpos + 1;
                     bwn_ok = j + 1 < whi;
                     bwn = sh.win[(j + 1) & (kWin - 1)][wl];
@@ -201,10 +201,10 @@ __device__ __forceinline__ void async_role_download(const EnvParams &p, AsyncSha
                     int32_t n = ke - kk;
                     if (n > lim - n_dl) n = lim - n_dl;
                     abrx::ChainState cs;
-                    cs.x = x; cs.d = 0.0; cs.inb = inb;
+                    cs.x = x; cs.eb = inb;
                     bool h = false;
                     const int32_t adds = abrx::chain_segment<abrx::STOP_GE>(cs, c, target, n, h);   // :160-163
-                    x = cs.x; inb = cs.inb;
+                    x = cs.x; inb = cs.eb;
                     n_dl += adds; kk += adds;
                     hit = h;
                     if (h || n_dl >= lim) state = DS_DONE;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void async_role_download(const EnvParams &p, AsyncSha
                     ke = async_itick(sh, gi, j + 1); ken = async_itick(sh, gi, j + 2);
                     tn = (tpos + 1 == tlen) ? 0 : tpos + 1;
                     k_start = d_k; kk = d_k; lim = mt - d_k;
-                    x = 0.0; n_dl = 0; inb = 0; hit = false;
+                    x = 0.0; n_dl = 0; inb = -1; hit = false;
                     bad = act >= p.n_rates;
                     if (bad) state = DS_DONE;              // nothing downloads: the record carries the verdict
                     else {

@@ -99,9 +99,29 @@ ABR_HD int32_t sat_i32(double v) {
 // download integration advances through trace intervals between segments).
 struct ChainState {
     double x;      // current value
-    double d;      // last in-binade increment (valid when inb >= 1)
-    int32_t inb;   // consecutive additions that stayed in one binade
+    int32_t eb;    // biased exponent of the binade the last real addition of the CURRENT constant started in
+                   // (it stayed inside iff x is still in that binade), or -1: none yet / the constant changed
 };
+
+// min / max of two non-NaN doubles in one instruction (fmin / fmax would canonicalise their operands first)
+ABR_HD double min_num(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (b < a) ? b : a;
+#endif
+}
+ABR_HD double max_num(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (b > a) ? b : a;
+#endif
+}
 
 // Is a jumped result y on the allowed side of lim?
 template <int STOP>
@@ -140,12 +160,14 @@ ABR_HD bool any_lane(bool v) {
 #endif
 }
 
-// One SEGMENT of a chain: one exact jump to the end of the binade / just before
-// the stop / the end of the budget, then one real addition (the one that crosses
-// the binade or satisfies the stop).  Performs at most n additions; returns how
-// many (>= 1 when n >= 1) and sets `hit` when the last one satisfied the STOP
-// predicate.  cs.inb counts the real in-binade additions just performed (only the
-// tie case needs one before it may jump); a caller that changes c resets it to 0.
+// One SEGMENT of a chain: one exact jump towards the end of the binade / the stop / the end of
+// the budget, then one real addition (the one that crosses the binade or satisfies the stop, or
+// simply the last of the budget).  Performs at most n additions; returns how many (>= 1 when
+// n >= 1) and sets `hit` when the last one satisfied the STOP predicate.  The jump always leaves
+// one addition of the budget for the real one, so a segment with n >= 1 ends in a real addition.
+// cs.eb remembers the binade that real addition started in: in the tie case a jump is allowed
+// only if the previous real addition of this constant stayed inside the binade x is in now
+// (header comment); a caller that changes c sets cs.eb = -1.
 // Straight-line selects on purpose: this is the body of the GPU hot loop.
 // BIAS (tests only) is added to the jump-length estimate: a non-zero value spoils it on purpose,
 // so that the repair path (estimate too long) and the short-jump path (estimate too short) run.
@@ -156,7 +178,7 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
 #endif
     const int32_t n = (n_in < kJumpCap) ? n_in : kJumpCap;   // see kJumpCap; callers loop until their budget is spent
     double x = cs.x;
-    int32_t inb = cs.inb, a = 0;
+    int32_t a = 0;
     const int e = expo(x);
     const bool normal = (e > 54) & (e < 2046);
     const int ec = normal ? e : 1000;                // keep the bit tricks in range when unused
@@ -165,9 +187,10 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
     const double base = pow2_biased(ec);
     const double dm = (base + ac) - base;            // RNE(|c| / u) * u
     const double rem = ac - dm;                      // exact, in [-u/2, u/2]
-    const double half_u = pow2_biased(ec - 53);
+    const double half_u = base * 0x1p-53;            // u/2 = 2^(e-53): exact (ec > 54)
     const bool tie = ((rem < 0.0) ? -rem : rem) == half_u;
-    const bool can = normal & (n > 0) & (expo(ac) < e) & (!tie | (inb >= 1));
+    const bool go = n > 0;
+    const bool can = normal & go & (expo(ac) < e) & (!tie | (cs.eb == e));
     const double d = (STOP == STOP_GE) ? dm : -dm;
     {
         // `lim` bounds the jumped results: they must stay inside the binade and before
@@ -177,20 +200,19 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
         double lim, gap;
         bool strict = true;              // results strictly beyond lim (else: may equal it)
         if (STOP == STOP_GE) {
-            const double top = pow2_biased(ec + 1);  // results stay < 2^(e+1) ...
-            lim = (thr < top) ? thr : top;           // ... and < thr
+            lim = min_num(thr, base + base);         // results stay < 2^(e+1) and < thr
             gap = lim - x;
         } else {
             if (STOP == STOP_LE) {
-                lim = (thr >= base) ? thr : base;    // results stay > 2^e and > thr
+                lim = max_num(thr, base);            // results stay > 2^e and > thr
             } else {
                 strict = !(thr > base);              // ... and >= thr
-                lim = (thr > base) ? thr : base;
+                lim = max_num(thr, base);
             }
             gap = x - lim;
         }
-        const int32_t room = can ? n : 0;
-        // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0); room <= kJumpCap.
+        const int32_t room = can ? n - 1 : 0;        // the last addition of the budget is a real one
+        // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0); room < kJumpCap.
         int32_t m0 = sat_i32(gap * rcp_est(dm));
         if (BIAS != 0) m0 = (m0 < 0x7fffff00 && m0 > -0x7fffff00) ? m0 + BIAS : m0;
         m0 = clamp0(m0, room);
@@ -227,19 +249,14 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
         x = xj;                          // == x when !can (m == 0)
         a = m;
     }
-    // ---- one real addition ----
-    const bool go = a < n;
+    // ---- one real addition (always, when there is a budget at all) ----
     const double xn = x + c;
-    const bool same = expo(xn) == expo(x);
-    inb = go ? (same ? inb + 1 : 0) : inb;
     const bool hit = go & stop_hit<STOP>(xn, thr);
     x = go ? xn : x;
     a += go ? 1 : 0;
-    cs.x = x; cs.inb = inb;
+    cs.x = x;
+    cs.eb = go ? e : cs.eb;              // "it stayed inside" is read off x's exponent by the next segment
     hit_out = hit;
-#ifdef ABR_SEGMENT_END_HOOK
-    ABR_SEGMENT_END_HOOK(STOP, a, n, hit, (!go) | same);
-#endif
     return a;
 }
 
@@ -252,7 +269,7 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
 template <int STOP, int BIAS = 0>
 ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out) {
     ChainState cs;
-    cs.x = x_io; cs.d = 0.0; cs.inb = 0;
+    cs.x = x_io; cs.eb = -1;
     int32_t a = 0;
     bool hit = false;
     while (a < n && !hit) a += chain_segment<STOP, BIAS>(cs, c, thr, n - a, hit);

@@ -128,7 +128,7 @@ ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
 constexpr int kDrainTail = ABR_K_DRAIN_TAIL;
 ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     ChainState cs;
-    cs.x = b_io; cs.d = 0.0; cs.inb = 0;
+    cs.x = b_io; cs.eb = -1;
     const double tail = (double)kDrainTail * sd;
     int32_t a = 0;
     bool below = false;
@@ -361,13 +361,15 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
                                double target) {
     // One flat loop over chain SEGMENTS (abr_exact_jump.h); a lane moves on to its next
     // trace interval between two segments.  The next interval's bandwidth and end tick
-    // are loaded one interval ahead so the loads overlap the arithmetic.
-    const int32_t lim = t.max_ticks - k;
-    int32_t ke = st.ke, ke_next = st.ke_next, tn = st.tn;
+    // are loaded one interval ahead so the loads overlap the arithmetic.  kk is the tick the
+    // next addition belongs to: download_time is G[kk - k] (:161); interval ends are clamped to
+    // max_ticks, so "ticks left in the interval" is also "ticks left at all".
+    const int32_t mt = t.max_ticks;
+    int32_t ke = st.ke < mt ? st.ke : mt, ke_next = st.ke_next, tn = st.tn;
     double c = st.c, bw_next = st.bw_next;
     ChainState cs;
-    cs.x = 0.0; cs.d = 0.0; cs.inb = 0;       // downloaded_size = 0 at a call site
-    int32_t n_dl = 0, kk = k;
+    cs.x = 0.0; cs.eb = -1;                   // downloaded_size = 0 at a call site
+    int32_t kk = k;
     bool hit = false;
     {
         // Prologue: downloaded_size starts at 0, so its first additions cross a binade
@@ -380,8 +382,8 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
 #pragma unroll
 #endif
         for (int i = 0; i < kPrologue; i++) x = x + c;
-        bool use = (ke - kk >= kPrologue) && (lim >= kPrologue) && (x < target);
-        if (use) { cs.x = x; n_dl = kPrologue; kk += kPrologue; }
+        bool use = (ke - kk >= kPrologue) && (x < target);
+        if (use) { cs.x = x; kk += kPrologue; }
         // A second chunk of plain additions, kept only if the first one was and it still fits the
         // interval and stays below the target: right after the first 16 ticks downloaded_size crosses
         // binades every ~1, 17, 33 ticks, where a whole loop trip buys the least.  Chunked, because an
@@ -393,11 +395,11 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
 #pragma unroll
 #endif
             for (int i = 0; i < kPrologue2; i++) x = x + c;
-            use = use && (ke - kk >= kPrologue2) && (lim - n_dl >= kPrologue2) && (x < target);
-            if (use) { cs.x = x; n_dl += kPrologue2; kk += kPrologue2; }
+            use = use && (ke - kk >= kPrologue2) && (x < target);
+            if (use) { cs.x = x; kk += kPrologue2; }
         }
     }
-    while (!hit && n_dl < lim) {
+    while (!hit && kk < mt) {
         // Interval over?  Its successor was prefetched.  Branch-free on purpose, and the
         // prefetch of the interval after that is (re)issued in EVERY trip: a load inside
         // a divergent `if` must be waited for at the end of that `if` (the loaded
@@ -405,20 +407,17 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
         // unconditionally it is only needed one trip later.
         const bool adv = kk >= ke;
         c = adv ? bw_next * kTickDt : c;
-        ke = adv ? ke_next : ke;
+        ke = adv ? (ke_next < mt ? ke_next : mt) : ke;
         s.j += adv ? 1 : 0;
         s.tpos = adv ? tn : s.tpos;
-        cs.inb = adv ? 0 : cs.inb;            // new constant: the steady state is void
+        cs.eb = adv ? -1 : cs.eb;             // new constant: the steady state is void
         tn = (s.tpos + 1 == s.tlen) ? 0 : s.tpos + 1;
-        bw_next = s.trace[tn];
-        ke_next = t.interval_tick[s.j + 2];
-        int32_t n = ke - kk;
-        if (n > lim - n_dl) n = lim - n_dl;
-        const int32_t adds = chain_segment<STOP_GE>(cs, c, target, n, hit);       // :160-163
-        n_dl += adds; kk += adds;
+        bw_next = s.trace[(uint32_t)tn];
+        ke_next = t.interval_tick[(uint32_t)(s.j + 2)];
+        kk += chain_segment<STOP_GE>(cs, c, target, ke - kk, hit);                // :160-163
     }
     Download d;
-    d.dl = cs.x; d.n_dl = n_dl; d.hit = hit;
+    d.dl = cs.x; d.n_dl = kk - k; d.hit = hit;
     return d;
 }
 
