@@ -2,7 +2,7 @@
 //
 // The product library (libabr_hip.so) is built without ABR_SPLIT_STAMPS: every macro below is then
 // empty and nothing of this file reaches its code object.  `make libabr_hip_stamps.so` defines it;
-// tools/gpu_stamps.py reads the accumulators through abr_debug_read_stamps / abr_debug_stamp_row
+// tools/gpu_stamps.py reads the accumulators through abr_debug_read_stamps
 // (profiles/r0*_role_stamps*.txt).
 #ifndef ABR_DIAG_STAMPS_H
 #define ABR_DIAG_STAMPS_H
@@ -39,25 +39,6 @@ __shared__ unsigned long long g_sh_st[3][33];
 #else
 #define ABR_STAMP_INIT()
 #define ABR_STAMP_FLUSH()
-#endif
-
-// per-role work / barrier-wait split of an iteration (two-wave kernel)
-#ifdef ABR_SPLIT_STAMPS
-#define SPLIT_STAMP_DECL long long st_work = 0, st_wait = 0, st_iters = 0;
-#define SPLIT_STAMP_T0 const long long st0 = __builtin_amdgcn_s_memtime();
-#define SPLIT_STAMP_T1 const long long st1 = __builtin_amdgcn_s_memtime();
-#define SPLIT_STAMP_T2 st_work += st1 - st0; st_wait += __builtin_amdgcn_s_memtime() - st1; st_iters++;
-// the unused 4th row of ep_qoe_terms: [work, wait, iterations] of D (slots 0-2) and P (slots 3-5)
-#define SPLIT_STAMP_OUT(base)                                                                       \
-    if (in_range && l < 3)                                                                           \
-        p.ep_qoe_terms[3 * p.n_lanes + (int64_t)blockIdx.x * 64 + l + (base)] =                      \
-            (double)(l == 0 ? st_work : (l == 1 ? st_wait : st_iters));
-#else
-#define SPLIT_STAMP_DECL
-#define SPLIT_STAMP_T0
-#define SPLIT_STAMP_T1
-#define SPLIT_STAMP_T2
-#define SPLIT_STAMP_OUT(base)
 #endif
 
 #endif

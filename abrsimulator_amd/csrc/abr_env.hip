@@ -5,8 +5,8 @@
 //         tick loop's float64 sequences advanced in exact closed form (abr_lane_jump.h,
 //         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout, 3 fused scripted rollout
 //   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
-//         service; abr_env_split3.h): what impl 3 (auto) runs up to 65 536 lanes
-//   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to 131 072 lanes
+//         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes lanes
+//   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to kSplitMaxLanes lanes
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
 //   K3    mpc_select_kernel<H, B>   mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H
 //   K4    episode_qoe_kernel        Simulator.py:79-86
@@ -726,334 +726,7 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------
-// K1, role-split form (impl 2; what impl 3 = auto resolves to up to kSplitMaxLanes lanes)
-// ---------------------------------------------------------------------------
-// Measured on MI355X (profiles/r02_valu_cost_microbench.txt): ONE wave on a SIMD issues a
-// vector instruction every 4.1-4.5 cycles (float64: 5.4-6.4) however independent its
-// instructions are; two waves per SIMD get 2.1 (3.7), four 1.6 (2.8).  65 536 lanes are 1 024
-// waves = one per SIMD, so the one-thread-per-lane kernel above leaves more than half of every
-// SIMD's issue slots empty at the headline size.  A lane's step has two halves that do not
-// need each other's float64 state (abr_lane_jump.h):
-//   D  the download: a pure function of (call-site tick, trace cursor, target size)
-//   P  the player:   buffer_level / play_time / counters over the download's ticks, the
-//                    completing tick, phase B, then reward / observation / history
-// so a workgroup is TWO waves over the same 64 lanes: wave 0 runs D of step s+1 while wave 1
-// runs P of step s.  The only thing D needs from P is the next call-site tick, which is
-// max(completion tick + 1, avail_tick[chunk + 1]) unless buffer_full gates the download
-// (Simulator.py:144).  D therefore SPECULATES "not gated"; P publishes its true call-site
-// tick every iteration and accepts a download record only if it started at exactly that tick.
-// A mis-speculated lane repeats that one download with the right tick in the next iteration
-// (one extra trip for that lane; nothing is ever rolled back in P, which only consumes
-// validated records).  One workgroup barrier per iteration; both waves run the same number
-// of iterations, so the barrier count always matches.
-// Workspace layout and results are those of the kernels above, bit for bit.
-struct SplitMail {
-    // D -> P, double-buffered by iteration parity
-    double dl[2][64];
-    int32_t n_dl[2][64], k_start[2][64], step[2][64], action[2][64], avail_next[2][64], flags[2][64];
-    // P -> D, double-buffered by iteration parity
-    int32_t fb_step[2][64], fb_k[2][64], fb_chunk[2][64], fb_episode[2][64], fb_alive[2][64];
-    int32_t any_alive[2];
-    // three-wave kernel only (abr_env_split3.h): the policy's draws for launch steps [act_hi - 64, act_hi), made
-    // ahead by the service wave; act[step % 64][lane]; act_hi is published AFTER the bytes (lds_st) and read
-    // BEFORE them (lds_ld).  0 = nothing there (the two-wave kernel).
-    uint8_t act[64][64];
-    int32_t act_hi;
-};
-constexpr int kRecValid = 1, kRecHit = 2, kRecBadAct = 4;
-
-// LDS words one wave writes while another reads them inside the same iteration (no barrier in between).
-// The LDS executes one wave's DS instructions in order, so "data, then counter" on the writer and "counter,
-// then data" on the reader need no s_waitcnt; the compiler just must not move them: relaxed atomics for the
-// counter, and a compiler-only barrier between it and the data.
-__device__ __forceinline__ int32_t lds_ld(const int32_t *w) {
-    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_st(int32_t *w, int32_t v) {
-    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#define ABR_LDS_ORDER() asm volatile("" ::: "memory")
-
-__device__ inline void lanej_store_player(const LaneJ &s, const EnvParams &p, int64_t i) {
-    p.buf[i] = s.buf; p.sumk[i] = s.sumk;
-    p.k[i] = s.k; p.chunk_id[i] = s.chunk_id; p.n_su[i] = s.n_su; p.n_rb[i] = s.n_rb;
-    p.n_play[i] = s.n_play; p.last_action[i] = s.last_action;
-    p.flags[i] = (uint8_t)((s.su ? kFlagStartUp : 0) | (s.be ? kFlagBufEmpty : 0) |
-                           (s.bf ? kFlagBufFull : 0) | kFlagArmed);
-    if (p.lane_speeds) { p.sd_lane[i] = s.sd; p.pt_lane[i] = s.pt; }
-    if (p.lane_speeds && p.speed_rows >= 2) { p.pl_left[i] = s.pl_left; p.play_id[i] = s.play_id; p.pt_sum[i] = s.pt_sum; }
-}
-
-// Wave 0 of a workgroup: the download side of its 64 lanes.  Executes exactly one workgroup
-// barrier per iteration, as split_role_player does, and leaves the loop in the same iteration.
-template <int MODE, bool ACT_RING = false>
-__device__ __forceinline__ void split_role_download(
-    const EnvParams &p, SplitMail &m, const int32_t *__restrict__ actions,
-    int32_t *__restrict__ actions_out, int32_t n_total, uint64_t seed) {
-    const int l = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 64 + l;
-    const bool in_range = i < p.n_lanes;
-    const int32_t V = p.video_length;
-    // The download wave is the critical one (15.3 k of 16.1 k cycles per iteration); priority outranks
-    // age in the SIMD's issue arbitration, so its instructions go first whenever they are ready.
-    // Same box, three interleaved pairs: 417.1 -> 405.1 us per launch (profiles/r03_ab_lds_staging.txt (4));
-    // in the three-wave kernel the ORDER D > P > S is worth 8 % (profiles/r03_ab_split3.txt)
-    __builtin_amdgcn_s_setprio(2);     // above the player wave (1 in the three-wave kernel, 0 in the two-wave one)
-    const abrx::Tables tb = make_tables(p);
-    abrx::Cursor cur; cur.j = 0; cur.tpos = 0; cur.tlen = 1; cur.trace = p.traces;
-    int32_t snap_j = 0, snap_tpos = 0;             // cursor before the download just issued
-    int32_t d_step = 0, d_k = 0, d_chunk = 0, d_ep = 0, offset0 = 0;
-    int32_t issued_step = -1, issued_k = -1;
-    bool d_alive = false, was_alive = false;
-    if (in_range) {
-        const int32_t t = p.trace_id[i];
-        offset0 = p.offset0[i];
-        cur.tlen = p.trace_len[t]; cur.trace = p.traces + p.trace_off[t];
-        cur.j = p.j[i]; cur.tpos = p.tpos[i];
-        d_k = p.k[i]; d_chunk = p.chunk_id[i]; d_ep = p.episode_no[i];
-        d_alive = was_alive = !p.done[i];
-    }
-    SPLIT_STAMP_DECL
-    ABR_STAMP_INIT();
-    for (int32_t t = 0;; t++) {
-        const int cb = t & 1;                      // this iteration's mailbox slot
-        SPLIT_STAMP_T0
-        // ---- download of step d_step, started at its (predicted) call site ----
-        int32_t flags = 0;
-        ABR_STAMP(0);
-        if (d_alive && d_step < n_total) {
-            snap_j = cur.j; snap_tpos = cur.tpos;
-            // (issuing these loads one iteration ahead, before the barrier, was measured twice and lost
-            // both times: two-wave kernel -1.6 %, 450.5 vs 443.9 us per launch, profiles/r02_ab_prefetch.txt;
-            // three-wave kernel, which has the registers for it, -3 %, profiles/r03_ab_split3.txt (6))
-            const abrx::StepStart st = abrx::lanej_begin_step(cur, tb, d_k, d_chunk);
-            ABR_STAMP(1);
-            int32_t a = -1;
-            bool drawn = false;
-            if (MODE == 1) a = actions[i];
-            else if (MODE == 3) a = actions[(int64_t)d_step * p.n_lanes + i];
-            else if (ACT_RING) {
-                // drawn ahead by S?  counter first, then the byte it vouches for
-                const int32_t hi = lds_ld(&m.act_hi);
-                ABR_LDS_ORDER();
-                drawn = d_step < hi && d_step >= hi - 64;
-                if (drawn) a = m.act[d_step & 63][l];
-            }
-            if (MODE == 2 && !drawn)
-                a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i), (uint32_t)d_chunk,
-                                           (uint32_t)d_ep, (uint32_t)p.n_rates);
-            if (MODE == 2 && actions_out) actions_out[(int64_t)d_step * p.n_lanes + i] = a;
-            flags = kRecValid;
-            abrx::Download d; d.dl = 0.0; d.n_dl = 0; d.hit = false;
-            ABR_STAMP(2);
-            if (a < 0 || a >= p.n_rates) flags |= kRecBadAct;
-            else d = abrx::lanej_download(cur, tb, st, d_k,
-                                          chunk_bitrate(p, d_chunk, a) * p.chunk_length /* :156 */);
-            ABR_STAMP(3);
-            if (d.hit) flags |= kRecHit;
-            m.dl[cb][l] = d.dl; m.n_dl[cb][l] = d.n_dl; m.k_start[cb][l] = d_k;
-            m.step[cb][l] = d_step; m.action[cb][l] = a; m.avail_next[cb][l] = st.avail_next;
-            issued_step = d_step; issued_k = d_k;
-            // ---- where the NEXT download starts, if nothing gates it ----
-            if (!d.hit) d_alive = false;           // bad action or max_ticks: the player retires the lane
-            else {
-                d_step++;
-                d_chunk++;
-                d_k = max(d_k + d.n_dl, st.avail_next);         // completing tick + 1, or availability (:143)
-                if (d_chunk >= V) {
-                    if (p.auto_reset) {            // a fresh episode: clock, cursor and chunk ids restart
-                        d_chunk = 0; d_ep++; d_k = tb.avail_tick[0];
-                        abrx::cursor_init(cur, offset0);
-                    } else d_alive = false;
-                }
-                // a call site at or past max_ticks never happens (the player times the lane out,
-                // and avail_tick is INT_MAX past the table): nothing to download speculatively
-                if (d_k >= tb.max_ticks) d_alive = false;
-            }
-        }
-        m.flags[cb][l] = flags;
-        ABR_STAMP(4);
-        SPLIT_STAMP_T1
-        __syncthreads();
-        SPLIT_STAMP_T2
-        ABR_STAMP(5);
-        if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
-        // ---- validate the record just issued against the player's true call site ----
-        if (!m.fb_alive[cb][l]) d_alive = false;
-        else if (issued_step != m.fb_step[cb][l] || issued_k != m.fb_k[cb][l]) {
-            // gated by buffer_full: take the player's word for where the download starts and
-            // redo it from the cursor it started from
-            d_alive = true;
-            d_step = m.fb_step[cb][l]; d_k = m.fb_k[cb][l];
-            d_chunk = m.fb_chunk[cb][l]; d_ep = m.fb_episode[cb][l];
-            if (issued_step == d_step) { cur.j = snap_j; cur.tpos = snap_tpos; }
-            issued_step = -1;
-        }
-    }
-    SPLIT_STAMP_OUT(0)
-    ABR_STAMP_FLUSH();
-    if (in_range && was_alive) { p.j[i] = cur.j; p.tpos[i] = cur.tpos; }
-}
-
-// Wave 1 of a workgroup: the player side (and all outputs) of the same 64 lanes.
-template <int MODE>
-__device__ __forceinline__ void split_role_player(
-    const EnvParams &p, SplitMail &m, float *__restrict__ obs_out, float *__restrict__ reward_out,
-    uint8_t *__restrict__ done_out, int32_t *__restrict__ actions_out, int32_t n_total) {
-    const int l = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 64 + l;
-    const bool in_range = i < p.n_lanes;
-    const int32_t V = p.video_length;
-    const abrx::Tables tb = make_tables(p);
-    LaneJ s;
-    s.cur.j = 0; s.cur.tpos = 0; s.cur.tlen = 1; s.cur.trace = p.traces;
-    uint8_t done = 0;
-    int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, b_step = 0;
-    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, g_su_obs = 0.0, g_rb_obs = 0.0;
-    bool b_alive = false, was_done = true;
-    if (in_range) {
-        done = p.done[i];
-        was_done = done != 0;
-        lanej_load(s, p, i);
-        n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
-        last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
-        g_su_obs = p.G[n_su_obs]; g_rb_obs = p.G[n_rb_obs];
-        b_alive = !done;
-    }
-    SPLIT_STAMP_DECL
-    ABR_STAMP_INIT();
-    for (int32_t t = 0;; t++) {
-        const int cb = t & 1, pb = (t + 1) & 1;    // this iteration's / the previous one's slot
-        SPLIT_STAMP_T0
-        ABR_STAMP(8);
-        if (b_alive && b_step < n_total && t >= 1) {
-            const int32_t fl = m.flags[pb][l];
-            // accept the download only if it started at exactly this lane's call-site tick
-            if ((fl & kRecValid) && m.step[pb][l] == b_step && m.k_start[pb][l] == s.k) {
-                const int64_t o = (int64_t)b_step * p.n_lanes + i;
-                float *obs = obs_out ? obs_out + (int64_t)b_step * ABR_OBS_DIM * p.n_lanes : nullptr;
-                const int32_t a = m.action[pb][l];
-                if (fl & kRecBadAct) {
-                    done |= ABR_DONE_BADACT;
-                    if (reward_out) reward_out[o] = 0.0f;
-                    if (done_out) done_out[o] = done;
-                    write_obs_j(s, p, i, obs, last_bw);
-                    b_alive = false;
-                } else {
-                    abrx::Download d;
-                    d.dl = m.dl[pb][l]; d.n_dl = m.n_dl[pb][l]; d.hit = (fl & kRecHit) != 0;
-                    const int32_t prev_action = s.last_action;
-                    const int32_t chunk = s.chunk_id;
-                    ABR_STAMP(9);
-                    const abrx::StepResult r =
-                        abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
-                    ABR_STAMP(13);
-                    double var = 0.0;
-                    if (r.hit) {
-                        const int64_t h = (int64_t)chunk * p.n_lanes + i;
-                        p.bw_hist[h] = r.bw;                                   // :164
-                        p.action_hist[h] = (uint8_t)a;                         // :165
-                        last_bw = r.bw;
-                        hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
-                        hist_n = hist_n + 1.0;
-                        if (prev_action >= 0)
-                            var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
-                    }
-                    // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
-                    const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
-                    const double rew = p.wr * (g_rb - g_rb_obs) + p.ws * (g_su - g_su_obs) + p.wv * var;
-                    if (r.ended) done |= ABR_DONE_EPISODE;
-                    if (r.timeout) done |= ABR_DONE_TIMEOUT;
-                    if (reward_out) reward_out[o] = (float)rew;
-                    if (done_out) done_out[o] = done;
-                    n_su_obs = s.n_su; n_rb_obs = s.n_rb;
-                    g_su_obs = g_su; g_rb_obs = g_rb;
-                    ABR_STAMP(14);
-                    if (r.ended || r.timeout) {
-                        p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
-                        p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
-                        p.ep_qoe_terms[2 * p.n_lanes + i] =
-                            !p.lane_speeds ? lane_avg_latency(p, s.sumk, s.n_play)
-                            : (p.speed_rows >= 2 ? avg_latency_sched(s.pt, s.sumk, s.pt_sum, s.n_play)
-                                                 : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
-                        if (p.auto_reset && r.ended) {
-                            // re-arm: this step's obs is the new episode's first call site
-                            copy_episode_actions(p, i, V);
-                            abrx::lanej_init_player(s, tb);
-                            episode_no++;
-                            n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
-                            last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
-                            done = 0;
-                            if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
-                        }
-                    }
-                    ABR_STAMP(15);
-                    write_obs_j(s, p, i, obs, last_bw);
-                    if (done) b_alive = false;
-                    ABR_STAMP(16);
-                }
-                b_step++;
-            }
-        }
-        // ---- tell the download side where this lane really is ----
-        const bool more = b_alive && b_step < n_total;
-        m.fb_step[cb][l] = b_step; m.fb_k[cb][l] = s.k; m.fb_chunk[cb][l] = s.chunk_id;
-        m.fb_episode[cb][l] = episode_no; m.fb_alive[cb][l] = more ? 1 : 0;
-        const bool any = __any(more) != 0;
-        if (l == 0) m.any_alive[cb] = any ? 1 : 0;
-        ABR_STAMP(17);
-        SPLIT_STAMP_T1
-        __syncthreads();
-        SPLIT_STAMP_T2
-        ABR_STAMP(18);
-        if (!m.any_alive[cb]) break;               // wave-uniform, identical in both waves
-    }
-    SPLIT_STAMP_OUT(3)
-    ABR_STAMP_FLUSH();
-    if (in_range) {
-        if (!was_done) {
-            lanej_store_player(s, p, i);
-            p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
-            p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
-            p.done[i] = done;
-        }
-        // lanes that were already finished (or finished early) report their terminal record
-        // for the remaining steps
-        for (int32_t t2 = b_step; t2 < n_total; t2++) {
-            const int64_t o = (int64_t)t2 * p.n_lanes + i;
-            if (reward_out) reward_out[o] = 0.0f;
-            if (done_out) done_out[o] = done;
-            if (MODE == 2 && actions_out) actions_out[o] = -1;
-            write_obs_j(s, p, i, obs_out ? obs_out + (int64_t)t2 * ABR_OBS_DIM * p.n_lanes : nullptr,
-                        last_bw);
-        }
-    }
-}
-
-// MODE 1: one externally supplied action per lane; MODE 2: fused random-policy rollout;
-// MODE 3: fused rollout of scripted actions [n_steps][n_lanes]
-//
-// Barrier discipline: the per-iteration workgroup barrier sits at two call sites, one in each role
-// function, reached through the wave-uniform branch below.  That is well defined on this target -- a
-// wave is entirely in one role, s_barrier counts WAVES, and both role loops execute exactly one barrier
-// per iteration and leave in the same iteration (the exit flag is written before the barrier and read by
-// both after it) -- but it relies on the branch staying wave-uniform: never split a role across a wave.
-// A mismatch would show as a hang, which the max_ticks / timeout parity tests (tests/test_env_gpu.py:
-// test_timeouts_are_identical_on_every_implementation, tests/test_async_gpu.py) turn into a failure.
-template <int MODE>
-__global__ __launch_bounds__(128) void env_split_kernel(
-    EnvParams p, const int32_t *__restrict__ actions, float *__restrict__ obs_out,
-    float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
-    int32_t *__restrict__ actions_out, int32_t n_steps, uint64_t seed) {
-    __shared__ SplitMail m;
-    const int32_t n_total = (MODE >= 2) ? n_steps : 1;
-    // the role is wave-uniform: each wave runs exactly one of the two loops
-    if (threadIdx.x < 64) split_role_download<MODE>(p, m, actions, actions_out, n_total, seed);
-    else split_role_player<MODE>(p, m, obs_out, reward_out, done_out, actions_out, n_total);
-}
-
-#include "abr_env_split3.h"
+#include "abr_env_roles.h"     // K1, role-split form: env_split3_kernel (three waves per 64 lanes), env_split_kernel (two)
 #ifdef ABR_WITH_ASYNC
 #include "abr_env_async.h"      // diagnostic build only (libabr_hip_async.so): the asynchronous pipeline `auto` never picks
 #endif
@@ -1378,14 +1051,13 @@ extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
 
 static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 
-// The role-split kernels win while the one-thread-per-lane form would leave SIMDs with one or two
-// waves (65 536 lanes: 7.2e9 vs 6.2e9 env-steps/s); from 262 144 lanes on the plain form has
-// enough waves of its own and no barrier (1.39e10 vs 1.32e10 at 1 M).  profiles/r02_sweeps.txt
-constexpr int64_t kSplitMaxLanes = 131072;
-// The three-wave form (abr_env_split3.h) wins while all its waves are resident: 3 x 1 024 waves of 101 VGPRs at
-// 65 536 lanes (8.26e9 vs 7.56e9 env-steps/s; 6.86e9 vs 6.34e9 with 20 decisions per launch); at 98 304 lanes and
-// beyond its workgroups no longer fit at once and it loses to the two-wave form.  profiles/r03_ab_split3.txt
+// Which kernel serves which size (same box, fused 48, profiles/r04_sweeps.txt): the three-wave role split while all its
+// waves are resident (3 x 1 024 waves at 65 536 lanes: 9.2e9 env-steps/s against 8.1e9 two-wave and 7.4e9 one thread per
+// lane); the two-wave role split up to 98 304 lanes (8.6e9 against 7.4e9 at 81 920; 8.8e9 against 8.7e9 at 98 304); one
+// thread per lane above (1.01e10 / 1.15e10 / 1.35e10 at 114 688 / 131 072 / 196 608 against 1.02e10 / 1.16e10 / 1.12e10):
+// it then has two or more waves per SIMD of its own and no barrier.
 constexpr int64_t kSplit3MaxLanes = 65536;
+constexpr int64_t kSplitMaxLanes = 98304;
 // The asynchronous pipeline (abr_env_async.h, impl 4) lost to the role-split kernels on MI355X (714 against 418 us
 // per launch at 65 536 lanes, profiles/r03_async_*) and `auto` never picked it: the product library is built
 // without it.  `make libabr_hip_async.so` (-DABR_WITH_ASYNC) keeps it selectable for the parity tests and records.
@@ -1532,7 +1204,6 @@ extern "C" int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream) 
 }
 
 #ifdef ABR_SPLIT_STAMPS
-extern "C" void *abr_debug_stamp_row(abr_env *env) { return env->p.ep_qoe_terms + 3 * env->p.n_lanes; }
 extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));

@@ -174,7 +174,7 @@ int abr_env_notify_restore(abr_env *env);
  * workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per 0.01 s tick;
  * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
  * time, history, reward, observation, episode end);
- * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 131 072 lanes,
+ * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 98 304 lanes,
  * 0 above.  All produce identical state and outputs (the workspace is interchangeable between
  * them); 1 exists as an independent cross-check.  4 (the asynchronous pipeline) is answered with
  * ABR_E_UNSUPPORTED by the product library. */

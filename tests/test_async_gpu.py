@@ -279,14 +279,20 @@ def test_async_falls_back_with_per_lane_speeds():
 
 def test_auto_resolves_to_the_measured_fastest():
     """`auto` is a measured choice: the three-wave role-split kernel up to 65 536 lanes, the
-    two-wave one up to 131 072, one thread per lane above -- for single steps and fused rollouts alike;
-    the asynchronous pipeline is opt-in."""
+    two-wave one up to 98 304, one thread per lane above -- for single steps and fused rollouts alike;
+    the asynchronous pipeline is not in the product library at all."""
     rng = np.random.default_rng(6)
     traces = _bench_like(rng, n_traces=4)
     env = make_env(BENCH_META, traces, 512)
     assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
     env = make_env(BENCH_META, traces, 65537)
     assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "split"
+    env = make_env(BENCH_META, traces, 98305)
+    assert env.effective_impl(fused=True) == "jump" and env.effective_impl(fused=False) == "jump"
+    import abrsimulator_amd as A
+    with pytest.raises(A._lib.AbrError):          # impl 4 is refused by the product library
+        _lib = A._lib.lib()
+        A._lib.check(_lib.abr_env_set_impl(env._h, 4), _lib)
 
 
 def test_per_chunk_ladders_on_the_async_pipeline(oracle):

@@ -24,18 +24,6 @@ for _ in range(3):
     env.step_random(48, 1, want_actions=False)
 torch.cuda.synchronize()
 print("impl", IMPL)
-if IMPL == "split":
-    fn = env.lib.abr_debug_stamp_row
-    fn.restype = C.c_void_p
-    fn.argtypes = [C.c_void_p]
-    row = env._view(fn(env._h), torch.float64, (N,)).cpu().numpy().reshape(-1, 64)[:, :6]
-    names = ["D work", "D wait", "D iters", "P work", "P wait", "P iters"]
-    for c, n in enumerate(names):
-        print(f"{n:8s} mean {row[:, c].mean():12.0f}  min {row[:, c].min():12.0f}  max {row[:, c].max():12.0f}")
-    it = row[:, 2].mean()
-    print(f"per iteration: D work {row[:,0].mean()/it:.0f} wait {row[:,1].mean()/it:.0f} | "
-          f"P work {row[:,3].mean()/it:.0f} wait {row[:,4].mean()/it:.0f} cycles; iterations/launch {it:.1f}")
-
 rd = env.lib.abr_debug_read_stamps
 rd.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * 32)()

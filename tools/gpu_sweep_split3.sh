@@ -1,5 +1,5 @@
 # which implementation wins where (same box): lanes x {split, split3, jump}, fused 48 and single steps
-mkdir -p gpurun_out/r03
+mkdir -p gpurun_out/r04
 S="--no-cpu-baseline --no-secondary --no-strong"
 for N in 16384 65536 98304 131072 196608 262144; do
   for I in split split3 jump; do
