@@ -314,7 +314,7 @@ def main():
                     events.append((e0, e1, 1))
         return run
 
-    def make_random_runner(env_, N_, F_, events_, use_graph):
+    def make_random_runner(env_, N_, F_, events_, use_graph, gather_on=True):
         """The env_random step loop over `env_`: launches of F_ fused decisions into double-buffered
         slabs; with more than one rank THE one collective of the path per launch -- ONE all-gather of
         the packed slab [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with
@@ -324,7 +324,7 @@ def main():
         slabs = [make_slab(F_, OBS_DIM, N_, dev) for _ in range(2)]
         bufs = [env_.bind_out(dict(obs=o, reward=r, done=torch.empty(F_, N_, dtype=torch.uint8, device=dev),
                                    actions=None)) for (_, o, r, _) in slabs]
-        gather = (world > 1 or force_dist) and not a.no_gather
+        gather = (world > 1 or force_dist) and not a.no_gather and gather_on
         gat_ = ObsRewardGather((OBS_DIM, N_), (F_, N_), dev) if gather else None
         graph = None
         if use_graph:
@@ -376,12 +376,16 @@ def main():
         return run_, gat_
 
     if a.workload == "env_random":
-        F = max(1, min(a.fuse, K))            # decisions actually fused into one launch
-        if (world > 1 or force_dist) and not a.no_gather and not a.no_split_launch and K <= a.fuse and K >= 2:
+        F1 = max(1, min(a.fuse, K))           # decisions fused into one launch at N = 1 (what BENCH runs)
+        F = F1
+        if ((world > 1 or force_dist) and not a.no_gather and not a.no_split_launch and K <= a.fuse and K >= 2
+                and K % 2 == 0):
             # more than one rank and the whole timed region would be ONE launch: its all-gather would have
             # nothing to hide behind (the bracket closes right after it).  Two launches of K/2 decisions put
-            # the first gather under the second launch; only the second, smaller one stays exposed.
-            F = -(-K // 2)
+            # the first gather under the second launch; only the second, smaller one stays exposed.  (Even K
+            # only: both launches then use the pre-bound slabs and both are gathered.)  The `control` block of
+            # the JSON line separates what this change of launch shape costs from what the collective costs.
+            F = K // 2
         run, gat = make_random_runner(env, N, F, ev, a.graph and world == 1)
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"
@@ -466,6 +470,26 @@ def main():
 
     roof = env_roofline() if a.workload == "env_random" else mpc_roofline(avg_launch_s)
 
+    # ---- N > 1 only: what the collective costs and what the launch shape costs, measured in the same process
+    #      with the same bracket, so that the scaling curve can be read: (1) the SAME launches without the
+    #      all-gather; (2) the N = 1 launch shape (one launch of F1 decisions) without the all-gather ----
+    def control_block(env_, N_, F_used, total_lanes_):
+        out = {}
+        for name, f_ in (("same_launches_no_gather", F_used), ("n1_launch_shape_no_gather", F1)):
+            evc = []
+            runc, _ = make_random_runner(env_, N_, f_, evc, False, gather_on=False)
+            runc(min(W, 2 * f_), False)
+            reps = max(1, min(repeats, 12))
+            tc = float(np.median([timed_region(runc, K) for _ in range(reps)]))
+            lsc, _ = launch_stats(evc)
+            out[name] = {"value": total_lanes_ * K / tc, "ms_per_step": tc / K * 1e3, "fuse": f_,
+                         "launches_per_region": -(-K // f_), "avg_launch_us": lsc * 1e6, "repeats": reps}
+        return out
+
+    control = None
+    if a.workload == "env_random" and (world > 1 or force_dist) and not a.no_gather:
+        control = control_block(env, N, F, N * world)
+
     # ---- the other half of BASELINE.json's metric, same process, same JSON line ----
     secondary = None
     if a.workload == "env_random" and world == 1 and not a.no_secondary:
@@ -479,7 +503,10 @@ def main():
         secondary = {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
                      "steps": K2, "warmup": W2, "ms_per_step": el2 / K2 * 1e3,
                      "config": {"workload": "mpc", "lanes_per_gpu": N, "n_rates": 6, "horizon": 5,
-                                "combos_per_lane": 6 ** 5, "predictor": "harmonic"},
+                                "combos_per_lane": 6 ** 5, "predictor": "harmonic",
+                                # every select grows the lanes' history by `horizon` predictions (D9), as repeated
+                                # next_bitrate() calls do in the reference; round 2's loop restored it between selects
+                                "history_restore": False},
                      "roofline": mpc_roofline(ls2)}
 
     # ---- BASELINE.json configs[3] / north_star "1/2/4/8-GPU scaling curve on 1 048 576 lanes": the SAME job
@@ -500,9 +527,13 @@ def main():
         times_s = [timed_region(run_s, K) for _ in range(reps_s)]
         el_s = float(np.median(times_s))
         ls_s, _ = launch_stats(ev_s)
+        control_s = None
+        if (world > 1 or force_dist) and not a.no_gather:
+            control_s = control_block(env_s, Ns, F, STRONG_TOTAL)
         strong = {"metric": "env_steps_per_sec", "value": STRONG_TOTAL * K / el_s, "unit": "env-steps/s",
                   "scaling": "strong", "n_gpus": world, "total_lanes": STRONG_TOTAL, "lanes_per_gpu": Ns,
                   "steps": K, "ms_per_step": el_s / K * 1e3, "repeats": reps_s, "fuse": F,
+                  "launches_per_region": -(-K // F), "control": control_s,
                   "impl": env_s.effective_impl(fused=True), "avg_launch_us": ls_s * 1e6,
                   "collective": (f"1 all_gather_into_tensor per launch, {(8 + F) * Ns * 4} B per rank; issued "
                                  f"{gat_s.n_collectives}x" if gat_s else "none")}
@@ -523,7 +554,9 @@ def main():
             "scaling": "strong" if a.total_lanes else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": repeats, "repeat_seconds": times,
             "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
-                       "fuse": F, "impl": impl,
+                       "fuse": F, "launches_per_region": -(-K // F), "fuse_at_n1": F1 if a.workload == "env_random" else 1,
+                       "impl": impl,
+                       "history_restore": False if a.workload != "env_random" else None,
                        "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
                        "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
                        "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
@@ -535,6 +568,8 @@ def main():
                                       f"{gat.n_collectives if gat else 0}x" if gathering else "none")},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if control is not None:
+            line["control"] = control
         if secondary is not None:
             line["secondary"] = secondary
         if strong is not None:

@@ -524,3 +524,11 @@ def test_bench_default_line_carries_both_scaling_curves_two_ranks():
     st = line["strong_1048576"]
     assert st["scaling"] == "strong" and st["total_lanes"] == 16384 and st["lanes_per_gpu"] == 8192
     assert st["n_gpus"] == 2 and st["value"] > 0 and st["collective"].startswith("1 all_gather_into_tensor")
+    # what makes the first measured curve readable: the launch shape of every value is stated, and a control block
+    # separates the cost of the collective from the cost of cutting the N = 1 launch in two
+    assert line["config"]["launches_per_region"] == 2 and line["config"]["fuse_at_n1"] == 20
+    for blk in (line["control"], st["control"]):
+        a, b = blk["same_launches_no_gather"], blk["n1_launch_shape_no_gather"]
+        assert a["fuse"] == 10 and a["launches_per_region"] == 2 and a["value"] > 0
+        assert b["fuse"] == 20 and b["launches_per_region"] == 1 and b["value"] > 0
+    assert st["launches_per_region"] == 2
