@@ -48,6 +48,7 @@ class BatchedMPCController:
         # run the predictor as its own kernel (False: everything in one kernel; same results)
         self.use_scratch = os.environ.get("ABR_MPC_SINGLE_KERNEL") != "1"
         self._scratch = None
+        self._bound = None             # (key, config, options): rebuilt only when N / tables / weights change
         self.player = None
         self._tables_for = None
         if player is not None:
@@ -61,9 +62,11 @@ class BatchedMPCController:
     def update_mpd(self):
         self.mpd = self.player.get_mpd()
         self._tables_for = None
+        self._bound = None
 
     def update_qoe(self):
         self.qoe = self.player.get_qoe_metric()
+        self._bound = None
 
     def default_bitrate_utility(self, bitrate):
         return bitrate
@@ -96,7 +99,6 @@ class BatchedMPCController:
         """mpc.py:181-186, batched: returns int32 [N] bitrate indices."""
         ci = self.player.get_next_chunk_info()
         br, sz = self._tables()
-        cfg = self.config()
         N = int(ci.chunk_number.numel())
         action = torch.empty(N, dtype=torch.int32, device=self.device)
         flat = torch.empty(N, dtype=torch.int32, device=self.device) if want_details else None
@@ -111,16 +113,24 @@ class BatchedMPCController:
                       (ci.hist_sum_inv, torch.float64)):
             if t.dtype != dt or t.device.type != "cuda":
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
-        opt = _lib.MpcOptions()
-        opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
+        # the config / options structs and the predictor's scratch are bound once per (lane count, tables, weights,
+        # method): a select is then the two kernel launches and nothing else on the host (BoundOut's counterpart)
+        key = (N, self._tables_for, self.horizon, self.clip_horizon, self.method, self.utility,
+               float(self.qoe.variance_weight), float(self.qoe.rebuffer_weight), float(self.qoe.startup_weight))
+        if self._bound is None or self._bound[0] != key:
+            cfg = self.config()
+            opt = _lib.MpcOptions()
+            opt.predictor, opt.utility = self.METHODS[self.method], self.UTILITIES[self.utility]
+            if self.use_scratch:
+                # scratch for the predictor pre-kernel (include/abr_env.h: abr_mpc_options.scratch_dev)
+                need = C.c_size_t()
+                _lib.check(self.lib.abr_mpc_scratch_bytes(C.byref(cfg), N, C.byref(need)))
+                if self._scratch is None or self._scratch.numel() < need.value:
+                    self._scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+                opt.scratch_dev, opt.scratch_bytes = self._scratch.data_ptr(), self._scratch.numel()
+            self._bound = (key, cfg, opt)
+        _, cfg, opt = self._bound
         opt.mask_is_done = mask_is_done
-        if self.use_scratch:
-            # scratch for the predictor pre-kernel (include/abr_env.h: abr_mpc_options.scratch_dev)
-            need = C.c_size_t()
-            _lib.check(self.lib.abr_mpc_scratch_bytes(C.byref(cfg), N, C.byref(need)))
-            if self._scratch is None or self._scratch.numel() < need.value:
-                self._scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            opt.scratch_dev, opt.scratch_bytes = self._scratch.data_ptr(), self._scratch.numel()
         if self.method == "expsmoothing":
             hist, hlen = ci.previous_bandwidths, ci.history_length
             if hist.dtype != torch.float64 or hist.dim() != 2 or hist.shape[1] != N or hist.stride(1) != 1:

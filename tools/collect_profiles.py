@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise the round's evidence from gpurun_out/r03/ (scratch, written by tools/gpu_r03_final.sh on
+"""Summarise the round's evidence from gpurun_out/<round>/ (scratch, written by tools/gpu_r0N_final.sh on
 the GPU box) into profiles/ (tracked): rocprofv3 kernel stats, PMC summaries, bench JSON lines.
 
   python tools/collect_profiles.py --stage DIR   on the GPU box: DIR/*/.../*.csv -> DIR/summary.json
-  python tools/collect_profiles.py               here: gpurun_out/r03/ -> profiles/r03_*
+  python tools/collect_profiles.py               here: gpurun_out/<round>/ -> profiles/r03_*
 """
 import argparse
 import collections
@@ -14,7 +14,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r03"
+TAG = os.environ.get("ABR_ROUND_TAG", "r04")
 ENV_KERNEL = "env_split3_kernel<2>"
 MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
 LANES, FUSE = 65536, 48
@@ -70,7 +70,7 @@ def collect():
     keys = [k + t for t, _ in ENV_RUNS for k in ("fetch_", "write_")] + ["fetch_mpc", "write_mpc"]
     json.dump({k: s[k] for k in keys}, open(os.path.join(P, f"{TAG}_hbm_pmc_summary.json"), "w"), indent=1)
     # ---- HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read) ----
-    src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_r03_final.sh), "
+    src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_r0N_final.sh), "
            "per-launch averages in KB; FETCH_SIZE doubled (gfx950 reports half of a coalesced read, "
            "MI355X_MICROARCH.md 'HBM'; our 4-8 B/lane reads are outside the calibrated 16 B/lane case, "
            "so the read side is an upper estimate), WRITE_SIZE as read")

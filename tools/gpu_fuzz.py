@@ -4,8 +4,9 @@ buffer limits, start-up lengths, ragged traces with wrap-around) x random featur
 speed per lane, a speed schedule, per-chunk ladders) x kernel implementation (role-split with three / two waves, one thread per
 lane, asynchronous pipeline -- which serves the speed features through the role-split kernels) x call form
 (V single steps, or one fused scripted rollout), every lane's
-previous_bandwidths (float64 ==), final clocks / buffer / play_time (==), play_id (==) and episode
-QoE (1e-10) against the C oracle.   usage: python tools/gpu_fuzz.py [n_seeds] [lanes]"""
+previous_bandwidths (float64 ==), EVERY per-step reward (== float32 of the value derived from the oracle's
+per-call-site rebuffer / start-up timers and the ladder rows, tests/helpers.py: expected_rewards), final clocks /
+buffer / play_time (==), play_id (==) and episode QoE (1e-10) against the C oracle.   usage: python tools/gpu_fuzz.py [n_seeds] [lanes]"""
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import abrsimulator_amd as A  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from test_lane_jump_cpu import _random_config  # noqa: E402
+from helpers import oracle_rewards  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
@@ -47,8 +49,8 @@ for seed in range(n_seeds):
         br = np.array(meta["ladder"])[None, :] * rng.uniform(0.7, 1.3, (V, B))
     cfg = O.env_cfg(meta["ladder"], meta["chunk_length"], V, meta["max_buffer"], meta["start_up_length"],
                     meta["interval"], meta["weights"], meta["speed"], br_table=br)
-    steps, bw, fin, _ = O.env_batch(cfg, traces, tid, off, actions, max_ticks=6_000_000, speeds=speeds,
-                                    want_steps=False)
+    steps, bw, fin, _ = O.env_batch(cfg, traces, tid, off, actions, max_ticks=6_000_000, speeds=speeds)
+    want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"], br_table=br)
     chunks = A.Chunk(meta["ladder"]) if br is None else [A.Chunk(list(r)) for r in br]
     mpd = A.MPD(V, meta["chunk_length"], meta["max_buffer"], meta["start_up_length"], chunks)
     sp = meta["speed"] if speeds is None else torch.from_numpy(speeds if speeds.ndim == 1 else speeds.T.copy())
@@ -57,12 +59,12 @@ for seed in range(n_seeds):
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
     acts = torch.from_numpy(actions).cuda()
     if fused:
-        env.step_script(acts.T.contiguous())
+        rew = env.step_script(acts.T.contiguous())["reward"].cpu().numpy().T
     else:
-        for s in range(V):
-            env.step(acts[:, s].contiguous())
+        rew = np.stack([env.step(acts[:, s].contiguous())[1].cpu().numpy().copy() for s in range(V)], 1)
     f = {k: v.cpu().numpy() for k, v in env.observe_f64().items()}
     b = int((env.history()[1].cpu().numpy().T != bw).sum())
+    b += int((rew != want_rew).sum())
     for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
         b += int((f[k] != fin[k]).sum())
     b += int((f["play_id"].astype(np.int32) != fin["play_id"]).sum())
@@ -77,6 +79,7 @@ for seed in range(n_seeds):
     env.close()
 print(json.dumps(dict(seeds=n_seeds, lanes_per_seed=N, lane_steps=lane_steps, mismatches=bad,
                       cases=feats, seconds=round(time.time() - t0, 1),
-                      compared="previous_bandwidths float64 ==, final global/rebuffer/start_up/play time, "
+                      compared="previous_bandwidths float64 ==, every per-step reward == float32(oracle-derived), "
+                               "final global/rebuffer/start_up/play time, "
                                "buffer_level, play_id ==, episode QoE 1e-10, average_latency 1e-9")))
 sys.exit(1 if bad else 0)

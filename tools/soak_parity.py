@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off soak on the GPU box: a fused random-policy rollout of N lanes x 48 decisions on the
 MI355X against the C oracle on the host cores, comparing EVERY lane's previous_bandwidths
-(float64, bit-exact), final clocks and buffer (bit-exact) and episode QoE (1e-10).
+(float64, bit-exact), every per-step reward (== float32 of the value derived from the oracle's per-call-site
+timers, tests/helpers.py: expected_rewards), final clocks and buffer (bit-exact) and episode QoE (1e-10).
 usage: python tools/soak_parity.py [n_lanes] [mixed|uniform] [impl]"""
 import json
 import os
@@ -14,7 +15,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import abrsimulator_amd as A  # noqa: E402
+from helpers import oracle_rewards  # noqa: E402
 import bench  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
@@ -28,11 +31,12 @@ env = A.BatchedABREnv(A.MPD(V, bench.L, bench.MAX_BUFFER, bench.START_UP, A.Chun
                       A.QOEMetric(*bench.WEIGHTS), A.NetworkInfo(bench.INTERVAL, traces), N, impl=impl)
 env.reset(torch.from_numpy(tid), torch.from_numpy(off))
 t0 = time.perf_counter()
-out = env.step_random(V, seed, out=dict(obs=None, reward=None, done=None,
-                                        actions=torch.empty(V, N, dtype=torch.int32, device="cuda")))
+out = env.step_random(V, seed, out=dict(obs=None, reward=torch.empty(V, N, dtype=torch.float32, device="cuda"),
+                                        done=None, actions=torch.empty(V, N, dtype=torch.int32, device="cuda")))
 torch.cuda.synchronize()
 t_gpu = time.perf_counter() - t0
 acts = out["actions"].cpu().numpy().T.copy()
+rew = out["reward"].cpu().numpy()                         # [V, N]
 bh = env.history()[1].cpu().numpy()                       # [V, N]
 f = {k: v.cpu().numpy() for k, v in env.observe_f64().items()}
 qoe = env.episode_qoe().cpu().numpy()
@@ -42,21 +46,23 @@ cores, _ = bench.host_cores()
 chunks = np.array_split(np.arange(N), cores * 4)
 
 def run(idx):
-    _, bw, fin, _ = O.env_batch(cfg, traces, tid[idx], off[idx], acts[idx], want_steps=False)
-    return idx, bw, fin
+    steps, bw, fin, _ = O.env_batch(cfg, traces, tid[idx], off[idx], acts[idx])
+    return idx, bw, fin, oracle_rewards(steps, fin, acts[idx], bench.WEIGHTS, ladder=bench.LADDER)
 
 t0 = time.perf_counter()
 bad = 0
 with ThreadPoolExecutor(cores) as ex:
-    for idx, bw, fin in ex.map(run, chunks):
+    for idx, bw, fin, want_rew in ex.map(run, chunks):
         bad += int((bh[:, idx].T != bw).sum())
+        bad += int((rew[:, idx].T != want_rew).sum())
         for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
             bad += int((f[k][idx] != fin[k]).sum())
         bad += int((~np.isclose(qoe[idx], fin["qoe"], rtol=1e-10, atol=0)).sum())
 t_cpu = time.perf_counter() - t0
 res = dict(lanes=N, impl=impl, decisions=N * V, mixed_traces=mixed, mismatches=bad, gpu_seconds=round(t_gpu, 4),
            oracle_seconds=round(t_cpu, 2), oracle_threads=cores,
-           compared="previous_bandwidths float64 [V,N] ==, final global/rebuffer/start_up/play time "
+           compared="previous_bandwidths float64 [V,N] ==, every per-step reward [V,N] == float32(oracle-derived), "
+                    "final global/rebuffer/start_up/play time "
                     "and buffer_level ==, episode QoE rtol 1e-10")
 print(json.dumps(res))
 sys.exit(1 if bad else 0)

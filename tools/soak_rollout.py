@@ -14,7 +14,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import abrsimulator_amd as A  # noqa: E402
+from helpers import oracle_rewards  # noqa: E402
 import bench  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
@@ -47,12 +49,15 @@ t0 = time.perf_counter()
 steps, bw, a_o, fin = O.env_batch_mpc(ecfg, mcfg, br, sz, traces, tid, off, threads=cores)
 t_cpu = time.perf_counter() - t0
 bad = int((acts != a_o).sum()) + int((bh != bw).sum())
+# every per-step reward == float32 of the oracle-derived value (the environment downloads from its single ladder)
+bad += int((out["reward"].cpu().numpy().T != oracle_rewards(steps, fin, a_o, bench.WEIGHTS, ladder=bench.LADDER)).sum())
 for k in ("global_time", "rebuffer_time", "start_up_time", "play_time", "buffer_level"):
     bad += int((f[k] != fin[k]).sum())
 bad += int((~np.isclose(qoe, fin["qoe"], rtol=1e-10, atol=0)).sum())
 print(json.dumps(dict(lanes=N, decisions=N * V, combos=N * (V - 1) * 6 ** H, rates_used=int(len(np.unique(a_o))),
                       mismatches=bad, gpu_seconds=round(t_gpu, 3), oracle_seconds=round(t_cpu, 1),
                       oracle_threads=cores,
-                      compared="actions ==, previous_bandwidths float64 ==, final clocks and buffer ==, "
+                      compared="actions ==, previous_bandwidths float64 ==, every per-step reward == float32(oracle-derived), "
+                               "final clocks and buffer ==, "
                                "episode QoE rtol 1e-10; traces 300-3000 points (wrap-around)")))
 sys.exit(1 if bad else 0)
