@@ -623,8 +623,12 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     // (profiles/r03_ab_split3.txt)
     DVars dv;                          // D's variables stay in registers (every wave sets them up: no value then
     role_d_begin(dv, p);               // depends on the role); P's and S's go through LDS between iterations
-    if (role == 0) __builtin_amdgcn_s_setprio(2);
-    else if (role == 1) { __builtin_amdgcn_s_setprio(1); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
+#ifndef ABR_PRIO_D
+#define ABR_PRIO_D 2
+#define ABR_PRIO_P 1
+#endif
+    if (role == 0) __builtin_amdgcn_s_setprio(ABR_PRIO_D);
+    else if (role == 1) { __builtin_amdgcn_s_setprio(ABR_PRIO_P); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
     else { SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {

@@ -139,14 +139,14 @@ ABR_HD bool jump_inside(double y, double lim, bool strict) {
 constexpr int32_t kJumpCap = 1 << 20;
 
 // min(max(v, 0), hi) for hi >= 0 in one instruction
-ABR_HD int32_t clamp0(int32_t v, int32_t hi) {
+ABR_HD uint32_t clamp0(int32_t v, int32_t hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int32_t r;
+    uint32_t r;
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
     return r;
 #else
     v = (v > 0) ? v : 0;
-    return (v < hi) ? v : hi;
+    return (uint32_t)((v < hi) ? v : hi);
 #endif
 }
 
@@ -180,8 +180,8 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
     double x = cs.x;
     int32_t a = 0;
     const int e = expo(x);
-    const bool normal = (e > 54) & (e < 2046);
-    const int ec = normal ? e : 1000;                // keep the bit tricks in range when unused
+    const bool normal = (e > 54) & (e < 2046);       // else: no jump; the values below are then unused (all stay finite
+    const int ec = e;                                // or NaN-free enough: base = 0 or tiny, d = |c|, and m0 is clamped to 0)
     const double ac = (STOP == STOP_GE) ? c : -c;    // |c|: the sign of c is fixed by the stop kind (see chain())
     // steady increment of this binade and the tie test (header comment)
     const double base = pow2_biased(ec);
@@ -213,9 +213,9 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
         }
         const int32_t room = can ? n - 1 : 0;        // the last addition of the budget is a real one
         // Jump length: estimate gap / dm, clamped to [0, room] (NaN and negatives -> 0); room < kJumpCap.
-        int32_t m0 = sat_i32(gap * rcp_est(dm));
-        if (BIAS != 0) m0 = (m0 < 0x7fffff00 && m0 > -0x7fffff00) ? m0 + BIAS : m0;
-        m0 = clamp0(m0, room);
+        int32_t m0s = sat_i32(gap * rcp_est(dm));
+        if (BIAS != 0) m0s = (m0s < 0x7fffff00 && m0s > -0x7fffff00) ? m0s + BIAS : m0s;
+        const uint32_t m0 = clamp0(m0s, room);
         // Exact settlement (x + m*d is exact while it stays inside the binade).  With the answer
         // m* = the longest jump that stays inside, the estimate satisfies m0 - 1 <= m* (see
         // kJumpCap), so candidate bs = m0 - 1 is inside and the answer is the last of bs, bs + 1,
@@ -226,20 +226,20 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
         // "candidate 0 is inside" is load-bearing, and it is not taken on trust: ok0 checks it,
         // and a lane whose estimate overshot walks back to the last inside candidate.  The vote
         // keeps that path out of the way (one compare and a scalar branch per segment).
-        const int32_t bs = (m0 > 0) ? m0 - 1 : 0;
+        const uint32_t bs = (m0 > 0) ? m0 - 1 : 0;   // a saturating subtraction
         const double y0 = x + (double)bs * d;
         const double y1 = y0 + d;
         const double y2 = y1 + d;
-        const bool t1 = (bs + 1 <= room) & jump_inside<STOP>(y1, lim, strict);
-        const bool t2 = (bs + 2 <= room) & jump_inside<STOP>(y2, lim, strict) & t1;
-        int32_t m = bs + (t1 ? 1 : 0) + (t2 ? 1 : 0);
+        const bool t1 = (bs + 1 <= (uint32_t)room) & jump_inside<STOP>(y1, lim, strict);
+        const bool t2 = (bs + 2 <= (uint32_t)room) & jump_inside<STOP>(y2, lim, strict) & t1;
+        int32_t m = (int32_t)(bs + (t1 ? 1 : 0) + (t2 ? 1 : 0));
         double xj = t2 ? y2 : (t1 ? y1 : y0);
         const bool ok0 = (bs == 0) | jump_inside<STOP>(y0, lim, strict);
 #ifdef ABR_BRACKET_HOOK
         ABR_BRACKET_HOOK(ok0);           // host-side analysis builds count overshooting estimates
 #endif
         if (any_lane(!ok0)) {
-            int32_t mm = ok0 ? 0 : bs;
+            int32_t mm = ok0 ? 0 : (int32_t)bs;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang loop unroll(disable) vectorize(disable)
 #endif

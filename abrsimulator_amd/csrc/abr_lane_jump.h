@@ -43,8 +43,16 @@ constexpr double kTickDt = 0.01;   // Simulator.py:133
 #ifndef ABR_K_DRAIN_TAIL
 #define ABR_K_DRAIN_TAIL 16
 #endif
-constexpr int kPrologue = ABR_K_PROLOGUE;   // plain additions at the start of a download (see lanej_download)
-constexpr int kPrologue2 = 24;              // ... and of the second chunk
+constexpr int kPrologue = ABR_K_PROLOGUE;   // (ABR_OLD_PROLOGUE builds only)
+constexpr int kPrologue2 = 24;
+#ifndef ABR_PCHUNKS
+#define ABR_PCHUNKS 12
+#endif
+#ifndef ABR_PCHECK
+#define ABR_PCHECK 0x892
+#endif
+constexpr int kPChunks = ABR_PCHUNKS;       // prologue of a download: up to 7 single additions + this many chunks of 8
+constexpr int kPCheck = ABR_PCHECK;         // bit q: a checkpoint after chunk q (the last chunk's bit must be set)
 
 struct Tables {
     const double *G;               // G[n] = dt added n times to 0.0 (global_time, download_time, ...)
@@ -371,6 +379,58 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
     cs.x = 0.0; cs.eb = -1;                   // downloaded_size = 0 at a call site
     int32_t kk = k;
     bool hit = false;
+#ifndef ABR_OLD_PROLOGUE
+    {
+        // Prologue: downloaded_size starts at 0, so its first additions cross a binade every 1, 2, 4, 8, ... steps,
+        // where a jump buys nothing (a 95-instruction trip for a handful of ticks).  The first ~40 additions are
+        // therefore PLAIN additions -- that IS the reference's sequence -- and they have to work for every lane: a
+        // wave pays its slowest lane, and with 64 lanes some call site always sits just before an interval end
+        // (rounds 2-3 kept the prologue only when it fitted the current interval: 16 % of downloads got none).
+        // The additions are n1 = ticks left in the current interval at c, then c2 = the next interval's constant.
+        // To keep the code straight-line the first a = n1 mod 8 additions are single predicated ones, which
+        // aligns the interval boundary with a chunk boundary; then kPChunks chunks of 8 with one constant each.
+        // Checkpoints (bit q of kPCheck: after chunk q) are kept while they stay below the target (the sequence
+        // increases, so nothing before a kept checkpoint reached it), within max_ticks, and inside the NEXT interval.
+        const int32_t left = ke - kk;                                  // ticks of the current interval, >= 1
+        const int32_t n1 = left > 0 ? left : 0;
+        const int32_t a = n1 & 7, q1 = n1 >> 3;                        // singles, then q1 whole chunks at c
+        const double c2 = bw_next * kTickDt;
+        const int32_t room2 = (ke_next < mt ? ke_next : mt) - ke;      // ticks of the next interval (clamped to max_ticks)
+        double x = 0.0, xb = 0.0;
+        int32_t T = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 7; i++) x = (i < a) ? x + c : x;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < kPChunks; q++) {
+            const double cq = (q < q1) ? c : c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int i = 0; i < 8; i++) x = x + cq;
+            if ((kPCheck >> q) & 1) {
+                // a checkpoint after Tq ticks is usable if it is below the target and either all in the current
+                // interval (Tq <= n1: then also within max_ticks, ke being clamped) or its part beyond n1 ends
+                // strictly inside the next interval.  Usability only ever turns off as q grows.
+                const int32_t Tq = a + 8 * (q + 1);
+                const bool ok = (x < target) & ((Tq <= n1) | (Tq - n1 < room2));
+                xb = ok ? x : xb;
+                T = ok ? Tq : T;
+            }
+        }
+        cs.x = xb;
+        // past the interval boundary?  then the cursor moves on here (the loop reloads the look-ahead from it)
+        const bool crossed = T > n1;
+        kk += T;
+        c = crossed ? c2 : c;
+        ke = crossed ? (ke_next < mt ? ke_next : mt) : ke;
+        s.j += crossed ? 1 : 0;
+        s.tpos = crossed ? tn : s.tpos;
+    }
+#else
     {
         // Prologue: downloaded_size starts at 0, so its first additions cross a binade
         // every 1, 2, 4, 8, ... steps, where a jump buys nothing.  Do the first
@@ -399,6 +459,7 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
             if (use) { cs.x = x; kk += kPrologue2; }
         }
     }
+#endif
     while (!hit && kk < mt) {
         // Interval over?  Its successor was prefetched.  Branch-free on purpose, and the
         // prefetch of the interval after that is (re)issued in EVERY trip: a load inside

@@ -1,0 +1,32 @@
+# Issue / wait accounting of the env kernel (SQ counters, one rocprofv3 --pmc pass per group): how busy the vector issue is,
+# how many lanes are active per vector instruction, how much of a wave's life is waiting.
+#   usage: bash tools/gpu_sq_util.sh outdir [bench args]
+O=$GRAFT_REPO_ROOT/$1; shift
+R=$GRAFT_REPO_ROOT
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
+           "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-strong --steps 480 --warmup 48 "$@" > $O/g$i.log 2>&1 || echo "group $i failed"
+done
+python3 - <<PY
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "env_" in k and "<2>" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    print(k, json.dumps({c: round(v) for c, v in m.items()}))
+    if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+        print("  lanes active per VALU instruction: %.1f" % (m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"] * 1.0))
+    if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
+        print("  wait fraction of wave-cycles: %.3f" % (m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]))
+    if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
+        print("  VALU issue utilisation (4 cycles x instr / SIMD / kernel cycles): %.3f" % (4 * m["SQ_INSTS_VALU"] / 1024 / m["GRBM_GUI_ACTIVE"]))
+PY

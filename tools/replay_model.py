@@ -78,3 +78,37 @@ for T in (4, 6, 8, 10, 12, 14, 16, 64):
         base = cost
     print(f"  T={T:3d}: {it:.3f} iterations  {tr:6.2f} trips  D cost {cost:7.0f}")
 print(f"  (T=64 is the shipped schedule: {base:.0f})")
+
+
+# ---- round 4: cost-class dealing of downloads across a bigger workgroup, priced before it is built ----
+# A workgroup of G lane groups (64 * G lanes, G download waves).  Every step the workgroup's 64 * G pending downloads are
+# dealt to the G download waves by predicted cost (here: an ORACLE predictor -- the true trip count -- i.e. the best any
+# predictor could do), each wave then pays the slowest of ITS 64 downloads.  Two ways to close a step:
+#   barrier   one workgroup barrier per step (the role-split protocol as it is): the step lasts as long as the slowest WAVE
+#   free      no rendezvous between the download waves at all (they run ahead on their own, which needs rings towards the
+#             player / service side as in the asynchronous pipeline): a wave's time is the sum of its own batches
+# D instructions per decision = trips * 95 + 400 (start / publish / validate) + deal (moving a 15-word job through LDS and
+# ranking it: ~150 per batch, amortised over its 64 lanes it is per wave-step).
+def dealing(G, deal_cost=150, trip=95, start=400):
+    Wg = W // G
+    crit_barrier = instr = 0.0
+    for wg in range(Wg):
+        t = g[wg * G:(wg + 1) * G].reshape(G * 64, V)          # trips of the workgroup's lanes, per step
+        srt = -np.sort(-t, axis=0)                             # per step: costs in descending order
+        per_wave = srt.reshape(G, 64, V).max(1)                # [G, V]: each dealt wave's slowest download
+        crit_barrier += per_wave.max(0).sum()                  # barrier per step: the slowest wave
+        instr += (per_wave * trip + start + deal_cost).sum()
+    n = Wg * V
+    return crit_barrier / n, instr / (n * G)
+
+
+print("cost-class dealing (oracle predictor) against the shipped schedule (G = 1: 64-lane workgroups, no dealing):")
+print("   G  lanes/WG  critical-path trips per step (barrier per step)  D instructions per decision per wave")
+for G in (1, 2, 4, 6, 8, 16):
+    if W % G:
+        continue
+    cb, ins = dealing(G, deal_cost=0 if G == 1 else 150)
+    print(f"  {G:2d}  {64 * G:7d}  {cb:10.2f}                                          {ins:8.0f}")
+print("   -> with a workgroup barrier per step the step lasts as long as the workgroup's slowest download wave, which\n"
+      "      holds the slowest lanes of ALL its groups: the critical path grows with G while the instruction count\n"
+      "      falls -- and a lone wave's instruction stream, not the SIMD's issue capacity, is what bounds the step.")
