@@ -130,12 +130,13 @@ ABR_HD bool jump_inside(double y, double lim, bool strict) {
     return strict ? (y > lim) : (y >= lim);
 }
 
-// Most additions one segment performs.  The jump-length estimate gap * v_rcp_f64(dm) carries the
-// reciprocal's relative error eps (measured on gfx950: tests/test_exact_jump_gpu.py); while the
-// true quotient is below 1 / (2 eps) the estimate is off by less than half a step, and a longer
-// one is cut to the segment's budget <= kJumpCap, which is then certainly not too long.  A run
-// of more than 2^20 equal additions inside one binade (2.9 hours of 0.01 s ticks) simply takes
-// one segment per 2^20 steps.
+// Most additions one segment performs.  The jump-length estimate gap * v_rcp_f64(dm) carries the reciprocal's
+// relative error eps (the hardware's double-precision reciprocal is a seed, good to a few parts in 2^24 at worst); while
+// the true quotient is below 1 / (2 eps) the estimate is off by less than half a step, and a longer one is cut to the
+// segment's budget <= kJumpCap, which is then certainly not too long.  So candidate 0 of the settlement below is always
+// inside -- and because that is an argument about an estimate, the settlement still checks it (ok0) and repairs an
+// overshoot in line; correctness never rests on eps, only speed does.  A run of more than 2^20 equal additions inside one
+// binade (2.9 hours of 0.01 s ticks) takes one segment per 2^20 steps (tests/test_exact_jump_gpu.py: jumps of 2^27 steps).
 constexpr int32_t kJumpCap = 1 << 20;
 
 // min(max(v, 0), hi) for hi >= 0 in one instruction

@@ -1,8 +1,9 @@
 """The DEVICE build of the exact chain (csrc/abr_exact_jump.h: v_rcp_f64 estimate, saturating
-convert, out-of-line exact search) against the naive one-addition-per-tick loop run on the host,
-through the diagnostic entry point abr_debug_chain.  estimate_bias = +4 / -4 spoils the
-jump-length estimate on purpose so that the fallback search (jump_fix) -- never reached by
-real inputs, whose estimates are within one of the answer -- runs on the device too."""
+convert, three-candidate settlement, in-line repair) against the naive one-addition-per-tick loop
+run on the host, through the diagnostic entry point abr_debug_chain.  estimate_bias = +4 / -4
+spoils the jump-length estimate on purpose: +4 makes candidate 0 land outside, so the repair path
+-- never entered by real inputs, whose estimates are within one of the answer -- runs on the
+device; -4 makes every jump shorter than it could be, which the next segment makes up for."""
 import ctypes as C
 
 import numpy as np
@@ -80,9 +81,9 @@ def test_ties_thresholds_and_wild_ranges_on_device(H):
 
 
 def test_very_long_jumps_on_device(H):
-    """Jumps of up to 2^27 steps inside one binade: the regime in which a reciprocal estimate
-    could be off by more than one (it is not: v_rcp_f64 is good to an ulp or so; the biased
-    runs prove that the fallback would repair it if it were)."""
+    """Runs of up to 2^27 equal additions inside one binade: the regime in which a reciprocal
+    estimate could be off by more than one.  A segment is capped at 2^20 additions (kJumpCap), below
+    which the estimate is off by less than half a step; the biased runs show the repair working."""
     x0 = np.array([1.0, 1.0, 1.5, 1024.0, 1.0, 3.0])
     c = np.array([2.0 ** -30, 2.0 ** -29 + 2.0 ** -52, 3 * 2.0 ** -31, 2.0 ** -17, 2.0 ** -28, 2.0 ** -27])
     n = np.array([1 << 27, (1 << 27) + 12345, 1 << 26, 1 << 27, 99_999_999, 1 << 27], np.int32)
