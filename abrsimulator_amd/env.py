@@ -5,6 +5,7 @@ Host Python only holds PyTorch-ROCm tensors and calls the C ABI
 (include/abr_env.h); all simulation runs in the HIP kernels of csrc/abr_env.hip.
 """
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -55,7 +56,7 @@ class BatchedABREnv:
         # only what `auto` can select plus the jump / split / tick cross-checks; impl="async" (the asynchronous
         # pipeline: measured slower, kept for the parity tests and records) lives in _lib.ASYNC_SO and is
         # loaded from there -- an ImportError if that diagnostic library has not been built.
-        if impl == "async" and library is None:
+        if impl == "async" and library is None and not os.environ.get("ABR_HIP_LIB"):
             library = _lib.ASYNC_SO
         self.lib = _lib.lib(library)
         self.device = torch.device(device)
