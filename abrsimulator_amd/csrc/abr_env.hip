@@ -582,11 +582,12 @@ __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i
     obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
 }
 
-// 128 VGPRs (48 B of scratch per lane) = four waves per SIMD instead of three at 138: measured
-// +8 % at 262 144 lanes, +5 % at 1 M (same box, profiles/r02_ab_prefetch.txt); five waves
-// (96 VGPRs) was tried as well
+// Waves per SIMD the one-thread-per-lane kernels are compiled for.  Round 2: four (128 VGPRs + 48 B of scratch) instead
+// of three at 138 VGPRs, +8 % at 262 144 lanes, +5 % at 1 M; a fifth then cost 30 % in spills.  Round 4's shorter segment
+// needs 103 VGPRs, so five waves (<= 102 VGPRs) cost one spilled register: +2 % at 131 072 lanes, +4 % at 1 M (1.89e10
+// env-steps/s); six (<= 85) -7 % (profiles/r04_ab_download_loop.txt (6))
 #ifndef ABR_JUMP_WAVES
-#define ABR_JUMP_WAVES 4
+#define ABR_JUMP_WAVES 5
 #endif
 #define ABR_JUMP_BOUNDS __launch_bounds__(64, ABR_JUMP_WAVES)
 template <int MODE>

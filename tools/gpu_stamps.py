@@ -35,6 +35,7 @@ regions = {1: "D begin_step loads", 2: "D philox", 3: "D download loop", 4: "D p
            0: "D validate+loop", 9: "P record read", 10: "P drain (download ticks)", 11: "P completing tick",
            12: "P phase B wait_call", 13: "P return", 14: "P div+hist+reward", 15: "P episode end", 16: "P obs out",
            17: "P feedback", 18: "P barrier wait", 8: "P loop",
-           20: "S loop", 21: "S service (split3)", 22: "S barrier wait"}
+           20: "S loop", 21: "S service (split3)", 22: "S barrier wait",
+           23: "P idle: up to the drain", 24: "P drain: segments", 25: "P drain: plain tail loop"}
 for k in sorted(regions):
     print(f"  [{k:2d}] {regions[k]:28s} {buf[k] / waves / 49:9.0f} cycles / wave / iteration")
