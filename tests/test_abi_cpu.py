@@ -182,3 +182,27 @@ def test_product_library_ships_only_selectable_kernels(L):
     hot = open(os.path.join(src, "abr_env.hip")).read()
     assert "#ifdef ABR_WITH_ASYNC\n#include \"abr_env_async.h\"" in hot
     assert "noinline" not in open(os.path.join(src, "abr_exact_jump.h")).read()
+
+
+def test_env_kernels_have_one_barrier_and_no_calls():
+    """Structural properties of the device code, read off the ISA (make asm, ~20 s): every role-split env kernel
+    holds exactly ONE s_barrier (the iteration loop and its barrier are written once, csrc/abr_env_roles.h) and
+    no env kernel calls a function (the out-of-line jump search of rounds 1-3 is gone from the download loop)."""
+    import subprocess
+    src = os.path.join(ROOT, "abrsimulator_amd", "csrc")
+    asm = os.path.join(src, "abr_env.s")
+    deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h"))]
+    if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["make", "-C", src, "-s", "asm"], check=True, capture_output=True, timeout=600)
+    text = open(asm).read()
+    kernels = {}
+    for m in re.finditer(r"^(_Z\d+env_(split3|split|jump|advance)_kernelILi(\d)E\w*):\s*;?.*?$(.*?)s_endpgm", text, re.S | re.M):
+        kernels[(m.group(2), int(m.group(3)))] = m.group(4)
+    assert {("split3", 1), ("split3", 2), ("split3", 3), ("split", 1), ("split", 2), ("split", 3),
+            ("jump", 0), ("jump", 1), ("jump", 2), ("jump", 3)} <= set(kernels)
+    for (kind, mode), body in kernels.items():
+        assert "s_swappc" not in body and "s_setpc" not in body, (kind, mode)
+        if kind in ("split3", "split"):
+            assert body.count("s_barrier") == 1, (kind, mode, body.count("s_barrier"))
+        else:
+            assert "s_barrier" not in body, (kind, mode)
