@@ -36,9 +36,25 @@ __shared__ unsigned long long g_sh_st[3][33];
                 if (g_sh_st[(threadIdx.x >> 6) % 3][q_])                                       \
                     atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]);             \
     } while (0)
+// K3: cycles per phase, lane 0 of every wave; kept in registers, added to the global accumulators (slots 26..30) at the end
+#define K3_STAMP_DECL long long k3_t_ = __builtin_amdgcn_s_memtime(); long long k3_d_[5] = {0, 0, 0, 0, 0};
+#define K3_STAMP(n)                                                                            \
+    do {                                                                                       \
+        const long long t_ = __builtin_amdgcn_s_memtime();                                     \
+        k3_d_[(n) - 26] = t_ - k3_t_;                                                          \
+        k3_t_ = t_;                                                                            \
+    } while (0)
+#define K3_STAMP_FLUSH()                                                                       \
+    do {                                                                                       \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)     /* a sample: one workgroup in 64 */ \
+            for (int q_ = 0; q_ < 5; q_++) atomicAdd(&g_st_acc[26 + q_], (unsigned long long)k3_d_[q_]); \
+    } while (0)
 #else
 #define ABR_STAMP_INIT()
 #define ABR_STAMP_FLUSH()
+#define K3_STAMP_DECL
+#define K3_STAMP(n)
+#define K3_STAMP_FLUSH()
 #endif
 
 #endif

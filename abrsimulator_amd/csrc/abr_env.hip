@@ -1494,6 +1494,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
                        !(p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0)));
     double *my = tab + (li < LPB ? li : 0) * per_lane;
 
+    K3_STAMP_DECL
     // ---- phase 1: the predictor, one thread per lane (mpc.py:81-93 / :72-79) -- or its result, when
     //      mpc_predict_kernel already ran it for every lane (p.pre_pred != nullptr) ----
     if (valid && pre == 0) {
@@ -1509,6 +1510,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         }
     }
     __syncthreads();
+    K3_STAMP(26);
     // ---- phase 2: the per-(level, rate) tables, 60 divisions per lane spread over T threads ----
     if (valid) {
         const int c = p.chunk[lane];
@@ -1531,6 +1533,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         }
     }
     __syncthreads();
+    K3_STAMP(27);
     // ---- phase 3: each thread walks its prefix, then enumerates its subtree ----
     Best best; best.x = -INFINITY; best.idx = 0x7fffffff;
     if (valid && heff_s[li] > 0) {
@@ -1589,6 +1592,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             }
         }
     }
+    K3_STAMP(28);
     // ---- phase 4: first arg-max of x = -J over the T prefixes of a lane (ascending prefix =
     //      ascending flat index), then the winning leaf inside the winning group.  Two LDS atomics
     //      and two barriers: the maximum of x as an order-preserving 64-bit key (ds_max_u64), then
@@ -1608,6 +1612,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     __syncthreads();
     if (li < LPB && key && key == bestK[li]) atomicMin(&bestF[li], best.idx);
     __syncthreads();
+    K3_STAMP(29);
     if (valid && pre == 0) {
         const unsigned long long bk = bestK[li];
         const unsigned long long bu = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
@@ -1631,6 +1636,8 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         if (p.flat_out) p.flat_out[lane] = have ? bf : -1;
         if (p.J_out) p.J_out[lane] = have ? -bx : NAN;
     }
+    K3_STAMP(30);
+    K3_STAMP_FLUSH();
 }
 
 static int validate_mpc(const abr_mpc_config *c) {
