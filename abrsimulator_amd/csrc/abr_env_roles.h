@@ -103,7 +103,7 @@ __device__ __forceinline__ long long pr_i64(const ParkWords &k, int &at) {
 }
 __device__ __forceinline__ double pr_f64(const ParkWords &k, int &at) { return __longlong_as_double(pr_i64(k, at)); }
 // [word][lane]: two words of a lane are 64 dwords apart, which is what ds_write2st64_b32 / ds_read2st64_b32 address
-// with two independent registers per instruction -- no gathering of values into aligned register quads
+// with two independent registers per instruction -- no gathering of values into aligned register quads.  Q = words / 4.
 template <int Q>
 __device__ __forceinline__ void park_store(uint32_t (*area)[64], const ParkWords &k) {
     const int l = threadIdx.x & 63;
@@ -623,12 +623,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     // (profiles/r03_ab_split3.txt)
     DVars dv;                          // D's variables stay in registers (every wave sets them up: no value then
     role_d_begin(dv, p);               // depends on the role); P's and S's go through LDS between iterations
-#ifndef ABR_PRIO_D
-#define ABR_PRIO_D 2
-#define ABR_PRIO_P 1
-#endif
-    if (role == 0) __builtin_amdgcn_s_setprio(ABR_PRIO_D);
-    else if (role == 1) { __builtin_amdgcn_s_setprio(ABR_PRIO_P); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
+    if (role == 0) __builtin_amdgcn_s_setprio(2);
+    else if (role == 1) { __builtin_amdgcn_s_setprio(1); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
     else { SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {
