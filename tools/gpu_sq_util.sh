@@ -1,6 +1,6 @@
 # Issue / wait accounting of the env kernel (SQ counters, one rocprofv3 --pmc pass per group): how busy the vector issue is,
 # how many lanes are active per vector instruction, how much of a wave's life is waiting.
-#   usage: bash tools/gpu_sq_util.sh outdir [bench args]
+#   usage: [KERNEL=substring] bash tools/gpu_sq_util.sh outdir [bench args]      (KERNEL defaults to the env kernels' `<2>` instances)
 O=$GRAFT_REPO_ROOT/$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $O
@@ -18,7 +18,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "env_" in k and "<2>" in k:
+        want = "${KERNEL:-}"
+        if (want and want in k) or (not want and "env_" in k and "<2>" in k):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
