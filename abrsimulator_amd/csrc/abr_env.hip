@@ -1276,7 +1276,7 @@ struct MpcLds {
 // idx is the flat index of the winning innermost GROUP (the B leaves that share their first
 // H-1 digits) -- the winning leaf inside it is resolved once per lane at the end -- or, when
 // a clipped horizon ends above the innermost level, of the winning leaf itself.
-struct Best { double x; int32_t idx; };
+struct Best { double x; int32_t idx; double m; };    // m: the running maximum of the level-(H-2) node being enumerated
 
 // Depth-first enumeration with prefix sharing: the partial sums of objective()
 // (mpc.py:144-156) after level i depend only on R[0..i], and are formed in the
@@ -1330,13 +1330,24 @@ __device__ __forceinline__ void mpc_dfs(const MpcLds &t, const double *bl, const
                 g = fmax(g, x);
             }
         }
-        if (g > best.x) { best.x = g; best.idx = flat; }
-    } else if constexpr (BC > 0 && LVL >= H - 2) {
-#pragma unroll
-        for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
+        // H >= 4: the B groups below one level-(H-2) node only feed that node's maximum (one v_max_f64
+        // per group); the arg-max bookkeeping (compare, three selects, index) is paid once per NODE,
+        // which is then named by its H-2 digits, and the first leaf below it that reaches the
+        // lane's maximum is found afterwards (mpc_resolve_group, one thread per group)
+        if constexpr (H >= 4) best.m = fmax(best.m, g);
+        else if (g > best.x) { best.x = g; best.idx = flat; }
     } else {
+        if constexpr (LVL == H - 2 && H >= 4) best.m = -INFINITY;
+        if constexpr (BC > 0 && LVL >= H - 2) {
+#pragma unroll
+            for (int r = 0; r < BC; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
+        } else {
 #pragma unroll 1
-        for (int r = 0; r < B; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
+            for (int r = 0; r < B; r++) mpc_node<LVL, H, BC, FULL, WVM>(t, bl, rl, r, q, v, rb, buf, br_prev, pd, flat, best);
+        }
+        if constexpr (LVL == H - 2 && H >= 4) {
+            if (best.m > best.x) { best.x = best.m; best.idx = flat; }
+        }
     }
 }
 
@@ -1370,9 +1381,10 @@ __device__ __forceinline__ void mpc_node(const MpcLds &t, const double *bl, cons
     }
 }
 
-// The first leaf of innermost group `gflat` whose x equals the group maximum `xbest`:
-// re-walks the H-1 fixed digits with the same operation sequence as the search, then
-// scans the B leaves in order.  Runs once per lane.
+// The first leaf of innermost group `gflat` whose x equals the lane's maximum `xbest`
+// (INT32_MAX: none): re-walks the H-1 fixed digits with the same operation sequence as the
+// search, then scans the B leaves in order.  Runs once per lane (H < 4) or once per group of
+// the winning level-(H-2) node.
 __device__ inline int32_t mpc_resolve_group(const MpcLds &t, int H, int32_t gflat, int prev0,
                                             double buf, double xbest) {
     const int B = t.B;
@@ -1396,7 +1408,7 @@ __device__ inline int32_t mpc_resolve_group(const MpcLds &t, int H, int32_t gfla
         const double x = ((q + b) - t.wv * (v + fabs(b - bp))) - t.wr * (rb + (t.rbt[lvl * B + r] - buf));
         if (x == xbest) return gflat * B + r;
     }
-    return gflat * B;     // unreachable: xbest was produced by this very arithmetic
+    return 0x7fffffff;    // not in this group
 }
 
 // Phase 1 of K3 for one lane: validates chunk / previous_bitrate, runs the throughput predictor
@@ -1485,10 +1497,11 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     __shared__ int32_t prev_s[16];    // previous_bitrate as the index Python would use (mpc.py:132,148)
     __shared__ unsigned long long bestK[16];   // phase 4: the lane's maximum of x = -J as an ordered key
     __shared__ int32_t bestF[16];              //          and the smallest flat index that reaches it
+    __shared__ int32_t bestL[16];              // phase 5 (H >= 4): the first leaf below the winning node that reaches it
     const int tid = threadIdx.x;
     const int li = tid / T;               // lane in block
     const int pre = tid - li * T;         // prefix id
-    if (threadIdx.x < 16) { bestK[threadIdx.x] = 0; bestF[threadIdx.x] = 0x7fffffff; }
+    if (threadIdx.x < 16) { bestK[threadIdx.x] = 0; bestF[threadIdx.x] = 0x7fffffff; bestL[threadIdx.x] = 0x7fffffff; }
     const int64_t lane = (int64_t)blockIdx.x * LPB + li;
     const bool valid = (li < LPB) && (lane < p.n_lanes) &&
                        !(p.mask && ((p.mask[lane] != 0) == (p.mask_is_done != 0)));
@@ -1535,7 +1548,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     __syncthreads();
     K3_STAMP(27);
     // ---- phase 3: each thread walks its prefix, then enumerates its subtree ----
-    Best best; best.x = -INFINITY; best.idx = 0x7fffffff;
+    Best best; best.x = -INFINITY; best.idx = 0x7fffffff; best.m = -INFINITY;
     if (valid && heff_s[li] > 0) {
         MpcLds t;
         t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
@@ -1594,7 +1607,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     }
     K3_STAMP(28);
     // ---- phase 4: first arg-max of x = -J over the T prefixes of a lane (ascending prefix =
-    //      ascending flat index), then the winning leaf inside the winning group.  Two LDS atomics
+    //      ascending flat index); the winning leaf is found in phase 5.  Two LDS atomics
     //      and two barriers: the maximum of x as an order-preserving 64-bit key (ds_max_u64), then
     //      the smallest flat index among the threads that hold it (ds_min_i32) -- the same winner
     //      as a left-to-right scan with strict `>` (round 2 used a pairwise tree: six barriers).
@@ -1613,28 +1626,62 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
     if (li < LPB && key && key == bestK[li]) atomicMin(&bestF[li], best.idx);
     __syncthreads();
     K3_STAMP(29);
-    if (valid && pre == 0) {
-        const unsigned long long bk = bestK[li];
-        const unsigned long long bu = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
-        const double bx = __longlong_as_double((long long)bu);
-        int32_t bf = bestF[li];
-        const bool have = bk != 0 && bf != 0x7fffffff;
-        const int he = heff_s[li];
-        int32_t act = -1;
-        if (have) {
-            if (he == H) {
+    // ---- phase 5: the lanes' results, by the first threads of the block (with `pre == 0` every wave
+    //      held one such thread and walked through the resolve; now the other waves skip it).
+    //      H >= 4: bestF names the winning level-(H-2) node; thread (lane i, group r) looks through
+    //      one of its B innermost groups for the first leaf that reaches the maximum. ----
+    if (H >= 4) {
+        if (tid < LPB * B) {
+            const int l2 = tid / B, r = tid - l2 * B;
+            const int64_t lane2 = (int64_t)blockIdx.x * LPB + l2;
+            const unsigned long long bk = bestK[l2];
+            const int32_t bf = bestF[l2];
+            // (a masked or out-of-range lane has bk == 0: none of its threads entered a key)
+            if (bk != 0 && bf != 0x7fffffff && heff_s[l2] == H) {
+                const unsigned long long bu = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
+                const double *my2 = tab + l2 * per_lane;
                 MpcLds t;
-                t.brv = my; t.rbt = my + HB; t.tdl = my + 2 * HB;
-                t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = he;
-                bf = mpc_resolve_group(t, H, bf, prev_s[li], p.buffer[lane], bx);
+                t.brv = my2; t.rbt = my2 + HB; t.tdl = my2 + 2 * HB;
+                t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = H;
+                const int32_t first = mpc_resolve_group(t, H, bf * B + r, prev_s[l2], p.buffer[lane2],
+                                                        __longlong_as_double((long long)bu));
+                if (first != 0x7fffffff) atomicMin(&bestL[l2], first);
             }
-            int32_t lead = 1;
-            for (int i = 1; i < he; i++) lead *= B;
-            act = bf / lead;                                   // int(result[0])  mpc.py:186
         }
-        p.action_out[lane] = (p.neg_to_zero && act < 0) ? 0 : act;
-        if (p.flat_out) p.flat_out[lane] = have ? bf : -1;
-        if (p.J_out) p.J_out[lane] = have ? -bx : NAN;
+        __syncthreads();
+    }
+    if (tid < LPB) {
+        const int l2 = tid;
+        const int64_t lane2 = (int64_t)blockIdx.x * LPB + l2;
+        const bool valid2 = (lane2 < p.n_lanes) && !(p.mask && ((p.mask[lane2] != 0) == (p.mask_is_done != 0)));
+        if (valid2) {
+            const unsigned long long bk = bestK[l2];
+            const unsigned long long bu = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
+            const double bx = __longlong_as_double((long long)bu);
+            int32_t bf = bestF[l2];
+            const bool have = bk != 0 && bf != 0x7fffffff;
+            const int he = heff_s[l2];
+            int32_t act = -1;
+            if (have) {
+                if (he == H) {
+                    if (H >= 4) {
+                        bf = bestL[l2];       // (always found: the maximum came out of this very arithmetic)
+                    } else {
+                        const double *my2 = tab + l2 * per_lane;
+                        MpcLds t;
+                        t.brv = my2; t.rbt = my2 + HB; t.tdl = my2 + 2 * HB;
+                        t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = he;
+                        bf = mpc_resolve_group(t, H, bf, prev_s[l2], p.buffer[lane2], bx);
+                    }
+                }
+                int32_t lead = 1;
+                for (int i = 1; i < he; i++) lead *= B;
+                act = bf / lead;                                   // int(result[0])  mpc.py:186
+            }
+            p.action_out[lane2] = (p.neg_to_zero && act < 0) ? 0 : act;
+            if (p.flat_out) p.flat_out[lane2] = have ? bf : -1;
+            if (p.J_out) p.J_out[lane2] = have ? -bx : NAN;
+        }
     }
     K3_STAMP(30);
     K3_STAMP_FLUSH();

@@ -106,6 +106,39 @@ def test_select_matches_oracle_seeded(oracle, B, H, N):
     assert np.array_equal(ci.hist_n.cpu().numpy(), hn_o) and np.array_equal(ci.hist_sum_inv.cpu().numpy(), hs_o)
 
 
+@pytest.mark.parametrize("B,H", [(6, 5), (4, 5), (6, 4), (5, 6), (6, 3), (3, 7), (6, 2)])
+@pytest.mark.parametrize("wv,wr", [(0.0, 0.0), (1.0, 0.0), (1.0, 4.3), (0.5, 4.3)])
+def test_exact_ties_resolve_to_the_first_combination(oracle, B, H, wv, wr):
+    """mpc.py:171-179 keeps the FIRST minimum of the brute-force grid.  A ladder whose upper rates coincide
+    (exactly representable values, same sizes) makes many combinations tie bit for bit at the optimum --
+    across leaves of a group, groups of a node, nodes of a thread and threads of a lane, which are the
+    four places the search kernel settles a tie in."""
+    rng = np.random.default_rng(B * 10 + H)
+    N, V, L, mb = 257, 24, 4.0, 20.0
+    lad = np.arange(1, B + 1, dtype=np.float64) * 0.5
+    lad[B - (B + 1) // 2:] = lad[-1]                      # the upper half of the ladder is one rate
+    br = np.tile(lad, (V, 1))
+    sz = br * L
+    chunk = rng.integers(0, V - H + 1, N).astype(np.int32)
+    prev = rng.integers(0, B, N).astype(np.int32)
+    buf = np.where(rng.random(N) < 0.3, 0.0, rng.integers(0, 6, N) * 2.5)
+    hn = np.full(N, 4.0)
+    hs = hn / np.where(rng.random(N) < 0.5, 64.0, 0.25)  # predicted throughput: plenty, or so little that every combination rebuffers
+    cfg = oracle.mpc_cfg(B, H, V, L, mb, wv, wr, 0.0)
+    hn_o, hs_o = hn.copy(), hs.copy()
+    act, flat, Jm, pred = oracle.mpc_select(cfg, br, sz, chunk, prev, buf, hn_o, hs_o)
+    ties = 0
+    for i in range(48):                                   # the case is what it claims to be
+        _, jmin, J = oracle.mpc_brute(cfg, br, sz, chunk[i], prev[i], buf[i], pred[i])
+        ties += int((J == jmin).sum() > 1)
+    assert ties > 0
+    ctl, ci = _controller(br, sz, L, mb, wr, wv, 0.0, H, chunk, prev, buf, hn, hs)
+    a = ctl.next_bitrate(want_details=True).cpu().numpy()
+    assert np.array_equal(ctl.last_J.cpu().numpy(), Jm)
+    assert np.array_equal(ctl.last_flat.cpu().numpy().astype(np.int64), flat)
+    assert np.array_equal(a, act)
+
+
 def test_horizon_clip_and_mask(oracle):
     """D12: near the video end the reference raises IndexError; clip_horizon
     defines H_eff = min(H, V - chunk).  Masked lanes are left untouched."""

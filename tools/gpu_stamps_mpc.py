@@ -38,7 +38,7 @@ rd(buf, 1)
 waves = (((N + 6) // 7 + 63) // 64) * 4          # the stamps build samples one workgroup in 64
 names = {26: "phase 1 (predictions -> LDS) + barrier", 27: "phase 2 (tables: 60 divisions per lane) + barrier",
          28: "phase 3 (prefix + enumeration)", 29: "phase 4 (arg-max: 2 LDS atomics, 2 barriers)",
-         30: "resolve + outputs (one thread per lane)"}
+         30: "phase 5 (first leaf of the winning node) + outputs"}
 tot = sum(buf[k] for k in names)
 print(f"{N} lanes, {K} selects, {e0.elapsed_time(e1) / K * 1e3:.1f} us per select between events; cycles per wave per launch:")
 for k in sorted(names):
