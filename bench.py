@@ -496,12 +496,16 @@ def main():
         ev2 = []
         player, ctl, hn0, hs0 = mpc_setup()
         run2 = mpc_runner(player, ctl, hn0, hs0, ev2, False)
-        K2, W2 = 100, 20
+        K2, W2 = 100, 100
         run2(W2, False)
-        el2 = timed_region(run2, K2)
+        # five regions of K2 selects, the median reported and all five kept: the first region after the env
+        # workload runs on a clock that is still settling (a 100-select region is 20 ms)
+        times2 = [timed_region(run2, K2) for _ in range(5)]
+        el2 = float(np.median(times2))
         ls2, _ = launch_stats(ev2)
         secondary = {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
                      "steps": K2, "warmup": W2, "ms_per_step": el2 / K2 * 1e3,
+                     "repeats": len(times2), "repeat_seconds": times2,
                      "config": {"workload": "mpc", "lanes_per_gpu": N, "n_rates": 6, "horizon": 5,
                                 "combos_per_lane": 6 ** 5, "predictor": "harmonic",
                                 # every select grows the lanes' history by `horizon` predictions (D9), as repeated
