@@ -59,7 +59,8 @@ def collect():
     G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
     s = json.load(open(os.path.join(G, "summary.json")))
     for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "sweeps.txt",
-                "role_stamps.txt", "role_stamps_split3.txt", "async_role_stats.txt"):
+                "role_stamps.txt", "role_stamps_split3.txt", "async_role_stats.txt", "mpc_phase_stamps.txt",
+                "mpc_sq_counters.txt"):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
     for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),

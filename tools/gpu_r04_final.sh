@@ -33,6 +33,7 @@ make -C abrsimulator_amd/csrc -s libabr_hip_stamps.so libabr_hip_astats.so 2>/de
 ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 split > $O/role_stamps.txt 2>&1 || true
 ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 split3 > $O/role_stamps_split3.txt 2>&1 || true
 ABR_HIP_LIB=libabr_hip_astats.so python tools/gpu_async_stats.py 65536 48 > $O/async_role_stats.txt 2>&1 || true
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps_mpc.py > $O/mpc_phase_stamps.txt 2>&1 || true
 tail -22 $O/role_stamps_split3.txt; cat $O/async_role_stats.txt
 exit 0
 fi
@@ -64,4 +65,5 @@ for tag in env env_f20; do
 done
 echo "sq done"
 cd $R
+KERNEL=mpc_select bash tools/gpu_sq_util.sh gpurun_out/r04/sq_util_mpc --workload mpc > $O/mpc_sq_counters.txt 2>&1 || true
 python tools/collect_profiles.py --stage $O
