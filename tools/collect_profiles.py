@@ -65,7 +65,7 @@ def collect():
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
     for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),
                       ("stats_mpc", "mpc_kernel_stats.csv"), ("stats_env_mpc", "env_mpc_kernel_stats.csv")):
-        fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True))
+        fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # (earlier runs of the round leave theirs behind)
         if fs:
             shutil.copy(fs[-1], os.path.join(P, f"{TAG}_{dst}"))
     keys = [k + t for t, _ in ENV_RUNS for k in ("fetch_", "write_")] + ["fetch_mpc", "write_mpc"]
