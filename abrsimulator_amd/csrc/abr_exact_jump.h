@@ -258,6 +258,9 @@ ABR_HD int32_t chain_segment(ChainState &cs, double c, double thr, int32_t n_in,
     cs.x = x;
     cs.eb = go ? e : cs.eb;              // "it stayed inside" is read off x's exponent by the next segment
     hit_out = hit;
+#ifdef ABR_SEGMENT_END_HOOK
+    ABR_SEGMENT_END_HOOK(STOP, a, n_in, hit, can && expo(x) == e);   // host-side analysis builds: how the segment ended
+#endif
     return a;
 }
 

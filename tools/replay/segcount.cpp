@@ -4,13 +4,19 @@
 #include <stdint.h>
 static thread_local int g_seg[3];
 #define ABR_SEGMENT_HOOK(STOP) (g_seg[STOP]++)
+// how each DOWNLOAD segment ended, in order: 'B' = it spent its whole budget (the rest of a trace interval) without
+// reaching the target and without leaving the binade -- a segment a multi-interval jump could absorb; 'X' = anything else
+static thread_local char g_end[256];
+static thread_local int g_nend;
+#define ABR_SEGMENT_END_HOOK(STOP, a, n, hit, inside) \
+    do { if ((STOP) == 0 && g_nend < 255) g_end[g_nend++] = ((a) == (n) && !(hit) && (inside)) ? 'B' : 'X'; } while (0)
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
 extern "C" int seg_episode(double interval, double L, int32_t V, double max_buffer, double start_up,
                            int32_t max_ticks, const double *ladder, const double *trace, int32_t tlen,
                            int32_t offset, const int32_t *actions, int32_t *ge_out, int32_t *le_out,
-                           int32_t *ndl_out) {
+                           int32_t *ndl_out, int32_t *merged_out) {
     static thread_local abrx::TickTables tt;
     static thread_local bool have = false;
     if (!have) {
@@ -27,11 +33,22 @@ extern "C" int seg_episode(double interval, double L, int32_t V, double max_buff
     if (!abrx::lanej_wait_call(s, t)) return -2;
     for (int step = 0; step < V; step++) {
         g_seg[0] = g_seg[1] = g_seg[2] = 0;
+        g_nend = 0;
         const int32_t k0 = s.k;
         abrx::StepResult sr = abrx::lanej_step(s, t, ladder[actions[step]] * L, actions[step]);
         if (sr.timeout) return -2;
         ge_out[step] = g_seg[0]; le_out[step] = g_seg[1] + g_seg[2];
         ndl_out[step] = s.k - k0;
+        // trips of a download loop whose trip is [absorb up to M whole 'B' intervals] + [one segment], M = 1, 2, 3, 255
+        static const int Ms[4] = {1, 2, 3, 255};
+        for (int q = 0; q < 4; q++) {
+            int trips = 0, run = 0;
+            for (int i = 0; i < g_nend; i++) {
+                if (g_end[i] == 'B' && run < Ms[q] && i + 1 < g_nend) { run++; continue; }   // absorbed into the next trip
+                trips++; run = 0;
+            }
+            merged_out[step * 4 + q] = trips;
+        }
     }
     return 0;
 }

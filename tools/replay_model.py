@@ -27,6 +27,7 @@ traces = B.synth_traces(False)
 tid, off = B.lane_assignment(0, N, traces)
 V = B.V
 ge = np.zeros((N, V), np.int32); le = np.zeros((N, V), np.int32); nd = np.zeros((N, V), np.int32)
+mg = np.zeros((N, V, 4), np.int32)
 lad = (C.c_double * 16)(*B.LADDER)
 acts = np.stack([philox_action(1, np.arange(N), s, 0, len(B.LADDER)) for s in range(V)], 1).astype(np.int32)
 for i in range(N):
@@ -34,7 +35,8 @@ for i in range(N):
     rc = lib.seg_episode(C.c_double(B.INTERVAL), C.c_double(B.L), V, C.c_double(B.MAX_BUFFER), C.c_double(B.START_UP),
                          32 * V * 400, lad, t.ctypes.data_as(C.c_void_p), len(t), int(off[i]),
                          acts[i].ctypes.data_as(C.c_void_p), ge[i].ctypes.data_as(C.c_void_p),
-                         le[i].ctypes.data_as(C.c_void_p), nd[i].ctypes.data_as(C.c_void_p))
+                         le[i].ctypes.data_as(C.c_void_p), nd[i].ctypes.data_as(C.c_void_p),
+                         mg[i].ctypes.data_as(C.c_void_p))
     assert rc == 0
 print(f"{N} lanes x {V} decisions: download trips mean {ge.mean():.2f} p50 {np.median(ge):.0f} p90 {np.percentile(ge, 90):.0f} "
       f"p99 {np.percentile(ge, 99):.0f} max {ge.max()};  drain segments mean {le.mean():.2f} p90 {np.percentile(le, 90):.0f} max {le.max()}")
@@ -112,3 +114,14 @@ for G in (1, 2, 4, 6, 8, 16):
 print("   -> with a workgroup barrier per step the step lasts as long as the workgroup's slowest download wave, which\n"
       "      holds the slowest lanes of ALL its groups: the critical path grows with G while the instruction count\n"
       "      falls -- and a lone wave's instruction stream, not the SIMD's issue capacity, is what bounds the step.")
+
+
+# ---- round 4: multi-interval jumps, priced.  Inside one binade the steady increment of EVERY trace interval is a multiple of
+# the same ulp, so x + sum(n_i * d_i) over whole intervals is exact as long as it stays inside the binade and below the target:
+# a trip could absorb up to M whole intervals (a handful of instructions each: d_i, the tie test, one multiply-add, one compare)
+# before its one real segment.  tools/replay/segcount.cpp marks the segments that spent a whole interval inside the binade. ----
+print("multi-interval jumps: download trips per step, mean over lanes / mean of the wave maximum (64 lanes):")
+print(f"  shipped (one interval or one binade per trip)   {ge.mean():5.2f} / {g.max(1).mean():5.2f}")
+for q, M in enumerate((1, 2, 3, "any")):
+    m = mg[:, :, q]
+    print(f"  up to {M!s:>3} whole intervals absorbed per trip      {m.mean():5.2f} / {m.reshape(W, 64, V).max(1).mean():5.2f}")
