@@ -1059,6 +1059,7 @@ static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 // it then has two or more waves per SIMD of its own and no barrier.
 constexpr int64_t kSplit3MaxLanes = 65536;
 constexpr int64_t kSplitMaxLanes = 98304;
+constexpr int64_t kSingleStepJumpLanes = 32768;     // above: one decision per launch goes to one thread per lane
 // The asynchronous pipeline (abr_env_async.h, impl 4) lost to the role-split kernels on MI355X (714 against 418 us
 // per launch at 65 536 lanes, profiles/r03_async_*) and `auto` never picked it: the product library is built
 // without it.  `make libabr_hip_async.so` (-DABR_WITH_ASYNC) keeps it selectable for the parity tests and records.
@@ -1067,10 +1068,15 @@ static inline bool async_eligible(const abr_env *env) {
     return !env->p.lane_speeds && env->p.video_length + 2 <= kAvailLds;
 }
 #endif
-// fused == true: step_random / step_script (n_steps decisions per launch)
+// fused == true: more than one decision per launch (step_random / step_script with n_steps > 1)
 static inline int effective_impl(const abr_env *env, bool fused = false) {
     int impl = env->impl;
     if (impl == 3) {
+        // ONE decision per launch (abr_env_step, the K1 launches of abr_env_step_mpc, a fused call of one
+        // step) is a single pass through download -> player -> service whatever the kernel, so the role
+        // pipeline has nothing to overlap: one thread per lane is as fast up to 32 768 lanes and 5-10 %
+        // faster at 65 536 (profiles/r04_sweeps_single_step.txt)
+        if (!fused && env->p.n_lanes > kSingleStepJumpLanes) return 0;
         if (env->p.n_lanes <= kSplit3MaxLanes) return 5;
         return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
     }
@@ -1134,7 +1140,7 @@ extern "C" int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs
 template <int MODE>
 static int launch_fused(abr_env *env, const int32_t *script, int32_t n_steps, uint64_t seed, float *obs,
                         float *rew, uint8_t *dn, int32_t *acts, hipStream_t st) {
-    const int impl = effective_impl(env, true);
+    const int impl = effective_impl(env, n_steps > 1);
     const int64_t N = env->p.n_lanes;
 #ifdef ABR_WITH_ASYNC
     if (impl == 4) {

@@ -271,10 +271,10 @@ def main():
     env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
                           auto_reset=True, lane_id_base=lane0, impl=a.impl)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    KERNELS = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>",
+               "jump": "env_jump_kernel<2>", "tick": "env_advance_kernel<2>"}
     impl = env.effective_impl(fused=True)      # what the library resolves --impl to for fused rollouts
-    env_kernel = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>",
-                  "jump": "env_jump_kernel<2>",
-                  "tick": "env_advance_kernel<2>"}[impl]
+    env_kernel = KERNELS[impl]                 # (re-read below once the decisions per launch are known)
 
     def barrier():
         if world > 1 or force_dist:
@@ -386,6 +386,8 @@ def main():
             # only: both launches then use the pre-bound slabs and both are gathered.)  The `control` block of
             # the JSON line separates what this change of launch shape costs from what the collective costs.
             F = K // 2
+        impl = env.effective_impl(fused=F > 1)     # launches of ONE decision resolve differently (abr_env.h)
+        env_kernel = KERNELS[impl]
         run, gat = make_random_runner(env, N, F, ev, a.graph and world == 1)
         units_per_step = N * world
         unit, metric = "env-steps/s", "env_steps_per_sec"
@@ -538,7 +540,7 @@ def main():
                   "scaling": "strong", "n_gpus": world, "total_lanes": STRONG_TOTAL, "lanes_per_gpu": Ns,
                   "steps": K, "ms_per_step": el_s / K * 1e3, "repeats": reps_s, "fuse": F,
                   "launches_per_region": -(-K // F), "control": control_s,
-                  "impl": env_s.effective_impl(fused=True), "avg_launch_us": ls_s * 1e6,
+                  "impl": env_s.effective_impl(fused=F > 1), "avg_launch_us": ls_s * 1e6,
                   "collective": (f"1 all_gather_into_tensor per launch, {(8 + F) * Ns * 4} B per rank; issued "
                                  f"{gat_s.n_collectives}x" if gat_s else "none")}
         del env_s

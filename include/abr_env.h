@@ -175,13 +175,15 @@ int abr_env_notify_restore(abr_env *env);
  * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
  * time, history, reward, observation, episode end);
  * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 98 304 lanes,
- * 0 above.  All produce identical state and outputs (the workspace is interchangeable between
+ * 0 above -- and 0 above 32 768 lanes for launches of ONE decision (abr_env_step, the per-decision
+ * launches of abr_env_step_mpc, a fused call with n_steps == 1).  All produce identical state and outputs (the workspace is interchangeable between
  * them); 1 exists as an independent cross-check.  4 (the asynchronous pipeline) is answered with
  * ABR_E_UNSUPPORTED by the product library. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 
 /* The implementation (0, 1, 2 or 5; never 3) the handle resolves to right now: fused != 0 for
- * abr_env_step_random / abr_env_step_script, 0 for abr_env_step. */
+ * abr_env_step_random / abr_env_step_script with more than one decision per call, 0 for launches of
+ * one decision (abr_env_step, abr_env_step_mpc, n_steps == 1). */
 int abr_env_get_effective_impl(abr_env *env, int32_t fused, int32_t *impl_out);
 
 /*

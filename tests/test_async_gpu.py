@@ -278,15 +278,33 @@ def test_async_falls_back_with_per_lane_speeds():
 
 
 def test_auto_resolves_to_the_measured_fastest():
-    """`auto` is a measured choice: the three-wave role-split kernel up to 65 536 lanes, the
-    two-wave one up to 98 304, one thread per lane above -- for single steps and fused rollouts alike;
+    """`auto` is a measured choice: for fused rollouts the three-wave role-split kernel up to
+    65 536 lanes, the two-wave one up to 98 304, one thread per lane above; for launches of ONE decision
+    (step, the K1 launches of step_mpc, a fused call of one step) one thread per lane above 32 768 lanes;
     the asynchronous pipeline is not in the product library at all."""
     rng = np.random.default_rng(6)
     traces = _bench_like(rng, n_traces=4)
     env = make_env(BENCH_META, traces, 512)
     assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
+    env = make_env(BENCH_META, traces, 32768)
+    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
+    env = make_env(BENCH_META, traces, 32769)
+    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "jump"
+    # ... and whichever serves a call, the state it leaves is the same: single steps (one thread per lane) and a
+    # fused rollout (three waves) of the same lanes agree bit for bit
+    env.reset()
+    env2 = make_env(BENCH_META, traces, 32769, impl="split3")
+    env2.reset()
+    acts = torch.from_numpy(rng.integers(0, 6, (3, 32769)).astype(np.int32)).cuda()
+    fused = env2.step_script(acts)
+    for s in range(3):
+        o, r, d = env.step(acts[s])
+        assert torch.equal(o, fused["obs"][s]) and torch.equal(r, fused["reward"][s]) and torch.equal(d, fused["done"][s])
+    one = env.step_script(acts[:1])                 # a fused call of ONE step takes the single-decision kernel too
+    two = env2.step_script(acts[:1])
+    assert torch.equal(one["obs"], two["obs"]) and torch.equal(one["reward"], two["reward"])
     env = make_env(BENCH_META, traces, 65537)
-    assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "split"
+    assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "jump"
     env = make_env(BENCH_META, traces, 98305)
     assert env.effective_impl(fused=True) == "jump" and env.effective_impl(fused=False) == "jump"
     import abrsimulator_amd as A
