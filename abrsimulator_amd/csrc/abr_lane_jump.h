@@ -37,14 +37,10 @@
 namespace abrx {
 
 constexpr double kTickDt = 0.01;   // Simulator.py:133
-#ifndef ABR_K_PROLOGUE
-#define ABR_K_PROLOGUE 16
-#endif
 #ifndef ABR_K_DRAIN_TAIL
 #define ABR_K_DRAIN_TAIL 16
 #endif
-constexpr int kPrologue = ABR_K_PROLOGUE;   // (ABR_OLD_PROLOGUE builds only)
-constexpr int kPrologue2 = 24;
+constexpr int kPrologue = 16;               // (the asynchronous pipeline's own prologue: diagnostic build only)
 #ifndef ABR_PCHUNKS
 #define ABR_PCHUNKS 12
 #endif
@@ -379,10 +375,9 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
     cs.x = 0.0; cs.eb = -1;                   // downloaded_size = 0 at a call site
     int32_t kk = k;
     bool hit = false;
-#ifndef ABR_OLD_PROLOGUE
     {
         // Prologue: downloaded_size starts at 0, so its first additions cross a binade every 1, 2, 4, 8, ... steps,
-        // where a jump buys nothing (a 95-instruction trip for a handful of ticks).  The first ~40 additions are
+        // where a jump buys nothing (a 95-instruction trip for a handful of ticks).  The first up to 7 + 8 kPChunks additions are
         // therefore PLAIN additions -- that IS the reference's sequence -- and they have to work for every lane: a
         // wave pays its slowest lane, and with 64 lanes some call site always sits just before an interval end
         // (rounds 2-3 kept the prologue only when it fitted the current interval: 16 % of downloads got none).
@@ -430,36 +425,6 @@ ABR_HD Download lanej_download(Cursor &s, const Tables &t, const StepStart &st, 
         s.j += crossed ? 1 : 0;
         s.tpos = crossed ? tn : s.tpos;
     }
-#else
-    {
-        // Prologue: downloaded_size starts at 0, so its first additions cross a binade
-        // every 1, 2, 4, 8, ... steps, where a jump buys nothing.  Do the first
-        // kPrologue additions as plain additions (that IS the reference's sequence) and
-        // keep them only if they all fit the first interval and stay below the target
-        // (the sequence is increasing, so no earlier one can have reached it).
-        double x = 0.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = 0; i < kPrologue; i++) x = x + c;
-        bool use = (ke - kk >= kPrologue) && (x < target);
-        if (use) { cs.x = x; kk += kPrologue; }
-        // A second chunk of plain additions, kept only if the first one was and it still fits the
-        // interval and stays below the target: right after the first 16 ticks downloaded_size crosses
-        // binades every ~1, 17, 33 ticks, where a whole loop trip buys the least.  Chunked, because an
-        // all-or-nothing 32- or 64-tick prologue falls back to nothing when it does not fit (round 2:
-        // -2 % / -5 %); same box: 16 + 16 +2.7 %, 16 + 24 +3.0 %, 16 + 16 + 16 +2.3 %, 16 + 16 + 32
-        // +1.2 %, 16 + 8 + 8 +1.1 % (profiles/r03_ab_split3.txt (5)).
-        {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int i = 0; i < kPrologue2; i++) x = x + c;
-            use = use && (ke - kk >= kPrologue2) && (x < target);
-            if (use) { cs.x = x; kk += kPrologue2; }
-        }
-    }
-#endif
     while (!hit && kk < mt) {
         // Interval over?  Its successor was prefetched.  Branch-free on purpose, and the
         // prefetch of the interval after that is (re)issued in EVERY trip: a load inside
