@@ -28,6 +28,7 @@ tid, off = B.lane_assignment(0, N, traces)
 V = B.V
 ge = np.zeros((N, V), np.int32); le = np.zeros((N, V), np.int32); nd = np.zeros((N, V), np.int32)
 mg = np.zeros((N, V, 4), np.int32)
+est = np.zeros((N, V, 2), np.float64)
 lad = (C.c_double * 16)(*B.LADDER)
 acts = np.stack([philox_action(1, np.arange(N), s, 0, len(B.LADDER)) for s in range(V)], 1).astype(np.int32)
 for i in range(N):
@@ -36,7 +37,7 @@ for i in range(N):
                          32 * V * 400, lad, t.ctypes.data_as(C.c_void_p), len(t), int(off[i]),
                          acts[i].ctypes.data_as(C.c_void_p), ge[i].ctypes.data_as(C.c_void_p),
                          le[i].ctypes.data_as(C.c_void_p), nd[i].ctypes.data_as(C.c_void_p),
-                         mg[i].ctypes.data_as(C.c_void_p))
+                         mg[i].ctypes.data_as(C.c_void_p), est[i].ctypes.data_as(C.c_void_p))
     assert rc == 0
 print(f"{N} lanes x {V} decisions: download trips mean {ge.mean():.2f} p50 {np.median(ge):.0f} p90 {np.percentile(ge, 90):.0f} "
       f"p99 {np.percentile(ge, 99):.0f} max {ge.max()};  drain segments mean {le.mean():.2f} p90 {np.percentile(le, 90):.0f} max {le.max()}")
@@ -125,3 +126,29 @@ print(f"  shipped (one interval or one binade per trip)   {ge.mean():5.2f} / {g.
 for q, M in enumerate((1, 2, 3, "any")):
     m = mg[:, :, q]
     print(f"  up to {M!s:>3} whole intervals absorbed per trip      {m.mean():5.2f} / {m.reshape(W, 64, V).max(1).mean():5.2f}")
+
+
+# ---- dealing with a predictor a kernel can afford (the oracle rows above sort by the TRUE trip count) ----
+def dealing_pred(G, key, deal_cost=150, trip=95, start=400):
+    Wg = W // G
+    crit = instr = 0.0
+    for wg in range(Wg):
+        t = g[wg * G:(wg + 1) * G].reshape(G * 64, V)
+        kk = key[wg * G * 64:(wg + 1) * G * 64]                 # [G*64, V]
+        order = np.argsort(-kk, axis=0, kind="stable")
+        srt = np.take_along_axis(t, order, axis=0)
+        per_wave = srt.reshape(G, 64, V).max(1)
+        crit += per_wave.max(0).sum()
+        instr += (per_wave * trip + start + deal_cost).sum()
+    n = Wg * V
+    return crit / n, instr / (n * G)
+
+
+print("dealing with affordable predictors (G = 4, 256-lane workgroups): D instructions per decision per wave")
+for name, key in (("oracle (true trips)", g.reshape(N, V).astype(np.float64)),
+                  ("target / current rate, 16 log classes", np.floor(4 * np.log2(np.maximum(est[:, :, 0], 1.0)))),
+                  ("target / mean of two intervals, 16 log classes", np.floor(4 * np.log2(np.maximum(est[:, :, 1], 1.0)))),
+                  ("target / current rate, exact sort", est[:, :, 0]),
+                  ("target only (the action)", np.repeat(acts[:, :, None], 1, 2)[:, :, 0].astype(np.float64))):
+    cb, ins = dealing_pred(4, key)
+    print(f"  {name:48s} {ins:7.0f}   (critical path {cb:5.2f} trips)")
