@@ -152,3 +152,9 @@ for name, key in (("oracle (true trips)", g.reshape(N, V).astype(np.float64)),
                   ("target only (the action)", np.repeat(acts[:, :, None], 1, 2)[:, :, 0].astype(np.float64))):
     cb, ins = dealing_pred(4, key)
     print(f"  {name:48s} {ins:7.0f}   (critical path {cb:5.2f} trips)")
+
+
+# ---- narrower lane groups: what a wave that serves fewer lanes would pay (the maximum over its lanes) ----
+print("lane-group width: download trips / drain segments per step (mean of the group maximum)")
+for wdt in (64, 32, 16, 8):
+    print(f"  {wdt:2d} lanes   {ge.reshape(N // wdt, wdt, V).max(1).mean():5.2f} / {le.reshape(N // wdt, wdt, V).max(1).mean():5.2f}")
