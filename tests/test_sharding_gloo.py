@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N>1 path on CPU: shard ranges, the global-lane
+"""world_size-2 and world_size-8 gloo tests of the N>1 path on CPU: shard ranges, the global-lane
 trace map, the counter-based policy under lane_id_base, and the one collective
 (all-gather of (obs, reward)).  The per-rank stepper here is the ORACLE (tests
 may use it; the product path is the HIP kernels, exercised by the -m gpu tests
@@ -87,10 +87,11 @@ def test_shard_range_partitions_exactly():
     assert shard_range(1048576, 8, 3) == (393216, 131072)
 
 
-def test_two_rank_gather_equals_unsharded(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])     # 8 = the widest run the driver launches (101 lanes: uneven shards of 13 and 12)
+def test_gather_over_ranks_equals_unsharded(tmp_path, world):
     out = str(tmp_path / "g")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     full_o, full_r = np.load(out + "_o.npy"), np.load(out + "_r.npy")
     ref_o, ref_r = _rollout(0, TOTAL, _traces())
     assert np.array_equal(full_o, ref_o) and np.array_equal(full_r, ref_r)
