@@ -5,10 +5,13 @@
 //         tick loop's float64 sequences advanced in exact closed form (abr_lane_jump.h,
 //         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout, 3 fused scripted rollout
 //   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
-//         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes lanes
+//         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes lanes -- for launches of more than
+//         one decision; a single decision per launch goes to env_jump_kernel above kSingleStepJumpLanes lanes
 //   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to kSplitMaxLanes lanes
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
-//   K3    mpc_select_kernel<H, B>   mpc.py:81-93,104-186   harmonic predictor + exhaustive B^H
+//   K3    mpc_select_kernel<H, B, WVM>   mpc.py:81-93,104-186   harmonic predictor (mpc_predict_kernel ahead of it when the
+//         caller provides scratch) + exhaustive B^H: B^2 threads per lane; tables in LDS, depth-first enumeration with
+//         prefix sharing, LDS arg-max over the threads, first-leaf search below the winning node
 //   K4    episode_qoe_kernel        Simulator.py:79-86
 //
 // Exactness contract: every quantity that feeds a decision in the
