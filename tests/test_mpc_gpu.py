@@ -175,6 +175,39 @@ def test_horizon_clip_and_mask(oracle):
     assert (a2[[1, 2, 3, 4]] == -1).all() and a2[0] >= 0 and a2[5] >= 0
 
 
+@pytest.mark.parametrize("B,H", [(6, 5), (4, 4)])
+def test_clipped_and_full_horizons_share_workgroups_with_ties(oracle, B, H):
+    """Lanes near the video end (clipped horizon: exact arg-min index kept per thread) and lanes with the whole
+    horizon (two-stage arg-max + first-leaf search) sit in the same workgroups, a fifth of them masked out, on a
+    ladder whose upper rates coincide: every lane's flat index / J / action equals the brute-force oracle's."""
+    rng = np.random.default_rng(B + 31 * H)
+    N, V, L, mb = 301, 16, 4.0, 20.0
+    lad = np.arange(1, B + 1, dtype=np.float64) * 0.5
+    lad[B - (B + 1) // 2:] = lad[-1]
+    br = np.tile(lad, (V, 1)); sz = br * L
+    chunk = rng.integers(0, V - 1, N).astype(np.int32)          # V - chunk >= 2: at least two steps left
+    prev = rng.integers(0, B, N).astype(np.int32)
+    buf = np.where(rng.random(N) < 0.3, 0.0, rng.integers(0, 6, N) * 2.5)
+    hn = np.full(N, 4.0); hs = hn / np.where(rng.random(N) < 0.5, 64.0, 0.25)
+    mask = (rng.random(N) > 0.2).astype(np.uint8)
+    ctl, ci = _controller(br, sz, L, mb, 4.3, 1.0, 0.0, H, chunk, prev, buf, hn, hs, clip=True)
+    ci.mask = torch.from_numpy(mask).cuda()
+    a = ctl.next_bitrate(want_details=True).cpu().numpy()
+    flat, J = ctl.last_flat.cpu().numpy(), ctl.last_J.cpu().numpy()
+    kinds = set()
+    for i in range(N):
+        if not mask[i]:
+            assert float(ci.hist_n[i]) == 4.0                   # untouched
+            continue
+        he = min(H, V - int(chunk[i]))
+        kinds.add(he)
+        pred, _, _ = oracle.mpc_predict_ns(H, hn[i], hs[i])
+        cfg = oracle.mpc_cfg(B, he, V, L, mb, 1.0, 4.3, 0.0)
+        f, Jm, _ = oracle.mpc_brute(cfg, br, sz, chunk[i], prev[i], buf[i], pred[:he])
+        assert int(flat[i]) == f and float(J[i]) == Jm and a[i] == f // B ** (he - 1), (i, he)
+    assert H in kinds and len(kinds) >= 3
+
+
 def test_mpc_drives_env_rollout(oracle):
     """8(f) rank 1: K3 reads the env's float64 state zero-copy and drives K1.
     Compared with the oracle env whose policy callback is the oracle MPC sharing
