@@ -6,7 +6,7 @@
 //         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout, 3 fused scripted rollout
 //   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
 //         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes lanes -- for launches of more than
-//         one decision; a single decision per launch goes to env_jump_kernel above kSingleStepJumpLanes lanes
+//         one decision; a single decision per launch goes to env_jump_kernel at every size
 //   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to kSplitMaxLanes lanes
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
 //   K3    mpc_select_kernel<H, B, WVM>   mpc.py:81-93,104-186   harmonic predictor (mpc_predict_kernel ahead of it when the
@@ -1062,7 +1062,6 @@ static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 // it then has two or more waves per SIMD of its own and no barrier.
 constexpr int64_t kSplit3MaxLanes = 65536;
 constexpr int64_t kSplitMaxLanes = 98304;
-constexpr int64_t kSingleStepJumpLanes = 32768;     // above: one decision per launch goes to one thread per lane
 // The asynchronous pipeline (abr_env_async.h, impl 4) lost to the role-split kernels on MI355X (714 against 418 us
 // per launch at 65 536 lanes, profiles/r03_async_*) and `auto` never picked it: the product library is built
 // without it.  `make libabr_hip_async.so` (-DABR_WITH_ASYNC) keeps it selectable for the parity tests and records.
@@ -1077,9 +1076,9 @@ static inline int effective_impl(const abr_env *env, bool fused = false) {
     if (impl == 3) {
         // ONE decision per launch (abr_env_step, the K1 launches of abr_env_step_mpc, a fused call of one
         // step) is a single pass through download -> player -> service whatever the kernel, so the role
-        // pipeline has nothing to overlap: one thread per lane is as fast up to 32 768 lanes and 5-10 %
-        // faster at 65 536 (profiles/r04_sweeps_single_step.txt)
-        if (!fused && env->p.n_lanes > kSingleStepJumpLanes) return 0;
+        // pipeline has nothing to overlap: one thread per lane is 3-8 % shorter per launch from 4 096 to
+        // 65 536 lanes under the random policy and 30 % under MPC's actions (profiles/r04_sweeps_single_step.txt)
+        if (!fused) return 0;
         if (env->p.n_lanes <= kSplit3MaxLanes) return 5;
         return env->p.n_lanes <= kSplitMaxLanes ? 2 : 0;
     }

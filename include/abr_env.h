@@ -175,7 +175,7 @@ int abr_env_notify_restore(abr_env *env);
  * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
  * time, history, reward, observation, episode end);
  * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 98 304 lanes,
- * 0 above -- and 0 above 32 768 lanes for launches of ONE decision (abr_env_step, the per-decision
+ * 0 above -- and 0 at every size for launches of ONE decision (abr_env_step, the per-decision
  * launches of abr_env_step_mpc, a fused call with n_steps == 1).  All produce identical state and outputs (the workspace is interchangeable between
  * them); 1 exists as an independent cross-check.  4 (the asynchronous pipeline) is answered with
  * ABR_E_UNSUPPORTED by the product library. */

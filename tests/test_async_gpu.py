@@ -280,14 +280,12 @@ def test_async_falls_back_with_per_lane_speeds():
 def test_auto_resolves_to_the_measured_fastest():
     """`auto` is a measured choice: for fused rollouts the three-wave role-split kernel up to
     65 536 lanes, the two-wave one up to 98 304, one thread per lane above; for launches of ONE decision
-    (step, the K1 launches of step_mpc, a fused call of one step) one thread per lane above 32 768 lanes;
+    (step, the K1 launches of step_mpc, a fused call of one step) one thread per lane at every size;
     the asynchronous pipeline is not in the product library at all."""
     rng = np.random.default_rng(6)
     traces = _bench_like(rng, n_traces=4)
     env = make_env(BENCH_META, traces, 512)
-    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
-    env = make_env(BENCH_META, traces, 32768)
-    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "split3"
+    assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "jump"
     env = make_env(BENCH_META, traces, 32769)
     assert env.effective_impl(fused=True) == "split3" and env.effective_impl(fused=False) == "jump"
     # ... and whichever serves a call, the state it leaves is the same: single steps (one thread per lane) and a
