@@ -16,7 +16,7 @@ static thread_local int g_nend;
 extern "C" int seg_episode(double interval, double L, int32_t V, double max_buffer, double start_up,
                            int32_t max_ticks, const double *ladder, const double *trace, int32_t tlen,
                            int32_t offset, const int32_t *actions, int32_t *ge_out, int32_t *le_out,
-                           int32_t *ndl_out, int32_t *merged_out, double *est_out) {
+                           int32_t *ndl_out, int32_t *merged_out, double *est_out, int32_t *adv_out) {
     static thread_local abrx::TickTables tt;
     static thread_local bool have = false;
     if (!have) {
@@ -38,6 +38,7 @@ extern "C" int seg_episode(double interval, double L, int32_t V, double max_buff
         {   // what a dealing kernel could know at the call site: the target and the look-ahead's bandwidths
             abrx::Cursor cc = s.cur;
             const abrx::StepStart st0 = abrx::lanej_begin_step(cc, t, s.k, s.chunk_id);
+            adv_out[step] = cc.j - s.cur.j;        // intervals the cursor was behind at this call site
             const double tgt = ladder[actions[step]] * L;
             est_out[step * 2 + 0] = tgt / st0.c;                                           // ticks at the current interval's rate
             est_out[step * 2 + 1] = tgt / (0.5 * (st0.c + st0.bw_next * abrx::kTickDt));   // ... at the mean of two intervals

@@ -29,6 +29,7 @@ V = B.V
 ge = np.zeros((N, V), np.int32); le = np.zeros((N, V), np.int32); nd = np.zeros((N, V), np.int32)
 mg = np.zeros((N, V, 4), np.int32)
 est = np.zeros((N, V, 2), np.float64)
+advs = np.zeros((N, V), np.int32)
 lad = (C.c_double * 16)(*B.LADDER)
 acts = np.stack([philox_action(1, np.arange(N), s, 0, len(B.LADDER)) for s in range(V)], 1).astype(np.int32)
 for i in range(N):
@@ -37,7 +38,7 @@ for i in range(N):
                          32 * V * 400, lad, t.ctypes.data_as(C.c_void_p), len(t), int(off[i]),
                          acts[i].ctypes.data_as(C.c_void_p), ge[i].ctypes.data_as(C.c_void_p),
                          le[i].ctypes.data_as(C.c_void_p), nd[i].ctypes.data_as(C.c_void_p),
-                         mg[i].ctypes.data_as(C.c_void_p), est[i].ctypes.data_as(C.c_void_p))
+                         mg[i].ctypes.data_as(C.c_void_p), est[i].ctypes.data_as(C.c_void_p), advs[i].ctypes.data_as(C.c_void_p))
     assert rc == 0
 print(f"{N} lanes x {V} decisions: download trips mean {ge.mean():.2f} p50 {np.median(ge):.0f} p90 {np.percentile(ge, 90):.0f} "
       f"p99 {np.percentile(ge, 99):.0f} max {ge.max()};  drain segments mean {le.mean():.2f} p90 {np.percentile(le, 90):.0f} max {le.max()}")
@@ -158,3 +159,11 @@ for name, key in (("oracle (true trips)", g.reshape(N, V).astype(np.float64)),
 print("lane-group width: download trips / drain segments per step (mean of the group maximum)")
 for wdt in (64, 32, 16, 8):
     print(f"  {wdt:2d} lanes   {ge.reshape(N // wdt, wdt, V).max(1).mean():5.2f} / {le.reshape(N // wdt, wdt, V).max(1).mean():5.2f}")
+
+
+# ---- how far the trace cursor lags at a call site (the look-ahead burst of lanej_begin_step covers kCatch intervals) ----
+h = np.bincount(np.minimum(advs.ravel(), 8), minlength=9)
+print("intervals the cursor is behind at a call site (share of call sites):",
+      "  ".join(f"{i}{'+' if i == 8 else ''}: {100.0 * c / advs.size:.1f} %" for i, c in enumerate(h)))
+wmax = advs.reshape(W, 64, V).max(1)
+print("  ... maximum over the 64 lanes of a wave:", "  ".join(f"{i}{'+' if i == 8 else ''}: {100.0 * c / wmax.size:.1f} %" for i, c in enumerate(np.bincount(np.minimum(wmax.ravel(), 8), minlength=9))))
