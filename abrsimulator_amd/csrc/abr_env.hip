@@ -1673,13 +1673,16 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             if (have) {
                 if (he == H) {
                     if (H >= 4) {
-                        bf = bestL[l2];       // (always found: the maximum came out of this very arithmetic)
+                        // always found: the maximum came out of this very arithmetic (else: the node's first leaf)
+                        const int32_t fl = bestL[l2];
+                        bf = (fl != 0x7fffffff) ? fl : bf * B * B;
                     } else {
                         const double *my2 = tab + l2 * per_lane;
                         MpcLds t;
                         t.brv = my2; t.rbt = my2 + HB; t.tdl = my2 + 2 * HB;
                         t.L = p.L; t.max_buffer = p.max_buffer; t.wv = p.wv; t.wr = p.wr; t.B = B; t.heff = he;
-                        bf = mpc_resolve_group(t, H, bf, prev_s[l2], p.buffer[lane2], bx);
+                        const int32_t fl = mpc_resolve_group(t, H, bf, prev_s[l2], p.buffer[lane2], bx);
+                        bf = (fl != 0x7fffffff) ? fl : bf * B;
                     }
                 }
                 int32_t lead = 1;
