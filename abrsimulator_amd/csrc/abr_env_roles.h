@@ -189,8 +189,10 @@ __device__ __forceinline__ void role_d_pre(DVars &v, const EnvParams &p, SplitMa
     ABR_STAMP(0);
     if (v.d_alive && v.d_step < n_total) {
         v.snap_j = v.cur.j; v.snap_tpos = v.cur.tpos;
-        // (issuing these loads one iteration ahead, before the barrier, was measured twice and lost both times:
-        // two-wave kernel -1.6 %, profiles/r02_ab_prefetch.txt; three-wave kernel -3 %, profiles/r03_ab_split3.txt (6))
+        // (issuing these loads one iteration ahead, before the barrier, was measured three times and lost every time:
+        // two-wave kernel -1.6 %, profiles/r02_ab_prefetch.txt; three-wave kernel -3 %, profiles/r03_ab_split3.txt (6);
+        // the one-barrier form of round 4 -2 %, profiles/r04_experiments_not_kept.txt (6): 133 VGPRs, and the download
+        // wave's 1.4 k cycles move into the player wave's share of the SIMD)
         const abrx::StepStart st = abrx::lanej_begin_step(v.cur, tb, v.d_k, v.d_chunk);
         ABR_STAMP(1);
         int32_t a = -1;
