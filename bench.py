@@ -393,7 +393,7 @@ def main():
         unit, metric = "env-steps/s", "env_steps_per_sec"
     else:
         F = 1
-        impl = env.effective_impl(fused=False)     # env_mpc launches K1 one decision at a time
+        impl = env.effective_impl(fused=False) if a.workload == "env_mpc" else None   # env_mpc launches K1 one decision at a time; `mpc` launches no env kernel
         player, ctl, hn0, hs0 = mpc_setup()
         run = mpc_runner(player, ctl, hn0, hs0, ev, a.workload == "env_mpc")
         if a.workload == "mpc":
