@@ -36,6 +36,22 @@ __shared__ unsigned long long g_sh_st[3][33];
                 if (g_sh_st[(threadIdx.x >> 6) % 3][q_])                                       \
                     atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]);             \
     } while (0)
+// when each role of each workgroup began and ended (s_memtime): [workgroup][0 = begin, 1 = D end, 2 = P end, 3 = S end]
+// [4 + role]: where that role's wave ran: HW_REG_XCC_ID << 16 | HW_REG_HW_ID (simd_id[5:4] cu_id[11:8] sh_id[12] se_id[15:13])
+__device__ unsigned long long g_wg_t[4096][8];
+#define ABR_WG_WHERE(role)                                                                     \
+    do {                                                                                       \
+        unsigned hw_, xcc_;                                                                    \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                      \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                    \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                      \
+            g_wg_t[blockIdx.x][4 + (role)] = ((unsigned long long)(xcc_ & 15) << 16) | (hw_ & 0xffff); \
+    } while (0)
+#define ABR_WG_TIME(slot)                                                                      \
+    do {                                                                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                      \
+            g_wg_t[blockIdx.x][slot] = (unsigned long long)__builtin_amdgcn_s_memtime();       \
+    } while (0)
 // K3: cycles per phase, lane 0 of every wave; kept in registers, added to the global accumulators (slots 26..30) at the end
 #define K3_STAMP_DECL long long k3_t_ = __builtin_amdgcn_s_memtime(); long long k3_d_[5] = {0, 0, 0, 0, 0};
 #define K3_STAMP(n)                                                                            \
@@ -50,6 +66,8 @@ __shared__ unsigned long long g_sh_st[3][33];
             for (int q_ = 0; q_ < 5; q_++) atomicAdd(&g_st_acc[26 + q_], (unsigned long long)k3_d_[q_]); \
     } while (0)
 #else
+#define ABR_WG_WHERE(role)
+#define ABR_WG_TIME(slot)
 #define ABR_STAMP_INIT()
 #define ABR_STAMP_FLUSH()
 #define K3_STAMP_DECL

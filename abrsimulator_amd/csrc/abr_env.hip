@@ -731,6 +731,7 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
 }
 
 #include "abr_env_roles.h"     // K1, role-split form: env_split3_kernel (three waves per 64 lanes), env_split_kernel (two)
+#include "abr_env_ring.h"      // K1, role-split form without a per-iteration barrier: env_ring3_kernel (round 5)
 #ifdef ABR_WITH_ASYNC
 #include "abr_env_async.h"      // diagnostic build only (libabr_hip_async.so): the asynchronous pipeline `auto` never picks
 #endif
@@ -989,8 +990,8 @@ extern "C" int abr_env_destroy(abr_env *env) {
 // 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl < 0 || impl > 5)
-        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 5 (split3)");
+    if (impl < 0 || impl > 6)
+        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto), 5 (split3) or 6 (ring3)");
 #ifndef ABR_WITH_ASYNC
     if (impl == 4)
         return fail(ABR_E_UNSUPPORTED, "impl 4 (the asynchronous pipeline) is not part of the product library: "
@@ -1088,12 +1089,15 @@ static inline int effective_impl(const abr_env *env, bool fused = false) {
     (void)fused;
     return impl;
 }
-static inline bool is_split(int impl) { return impl == 2 || impl == 5; }
+static inline bool is_split(int impl) { return impl == 2 || impl == 5 || impl == 6; }
 // launch of the role-split kernels: two waves per 64 lanes (impl 2) or three (impl 5)
 template <int MODE>
 static void launch_split(int impl, const EnvParams &p, const int32_t *actions, float *obs, float *rew, uint8_t *dn,
                          int32_t *acts, int32_t n_steps, uint64_t seed, hipStream_t st) {
-    if (impl == 5)
+    if (impl == 6)
+        hipLaunchKernelGGL(env_ring3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(64 * ABR_RING_WAVES), 0, st, p, actions, obs, rew,
+                           dn, acts, n_steps, seed);
+    else if (impl == 5)
         hipLaunchKernelGGL(env_split3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(192), 0, st, p, actions, obs, rew,
                            dn, acts, n_steps, seed);
     else
@@ -1217,6 +1221,14 @@ extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+#ifdef ABR_SPLIT_STAMPS
+extern "C" int abr_debug_read_wg_times(unsigned long long *out, int n_wg) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), (size_t)n_wg * 8 * sizeof(unsigned long long));
     return 0;
 }
 #endif

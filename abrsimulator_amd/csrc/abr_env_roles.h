@@ -54,9 +54,10 @@ constexpr int kS3Valid = 0x10000, kS3Hit = 0x100, kS3Bad = 0x200, kS3Ended = 0x4
               kS3Reset = 0x1000, kS3Timeout2 = 0x2000;
 
 // LDS words one wave writes while another reads them inside the same iteration (no barrier in between).
-// The LDS executes one wave's DS instructions in order, so "data, then counter" on the writer and "counter,
-// then data" on the reader need no s_waitcnt; the compiler just must not move them: relaxed atomics for the
-// counter, and a compiler-only barrier between it and the data.
+// A wave's DS instructions are issued in order, but that does NOT make an earlier full-wave write visible before a
+// later single-lane one (round 5, measured with a tightly polling reader: profiles/r05_ab_ring.txt): the writer waits
+// for its own LDS traffic (lds_writes_done) between the data and the counter that vouches for it, the reader branches
+// on the counter before it loads the data.  Relaxed atomics for the counter; the compiler must not move either side.
 __device__ __forceinline__ int32_t lds_ld(const int32_t *w) {
     return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -64,6 +65,11 @@ __device__ __forceinline__ void lds_st(int32_t *w, int32_t v) {
     __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 #define ABR_LDS_ORDER() asm volatile("" ::: "memory")
+__device__ __forceinline__ void lds_writes_done() {
+    ABR_LDS_ORDER();
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0), everything else untouched: this wave's LDS writes have been performed
+    ABR_LDS_ORDER();
+}
 
 // The kernel's EnvParams argument, read afresh from the kernarg segment (it is the first argument of both kernels).
 // Why: with ONE loop for all roles every loop-invariant uniform value any role needs -- some 130 scalar registers of
@@ -458,7 +464,9 @@ __device__ __forceinline__ void service_write_obs(const SVars &v, const EnvParam
 }
 
 // the record P left in slot `sl`: division, history, reward, done, observation, episode end
-__device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, SplitMail2 &m2, int sl,
+// (M2: SplitMail2, or the ring kernel's RingPS -- the same fields with more slots)
+template <class M2>
+__device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 &m2, int sl,
                                                float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                uint8_t *__restrict__ done_out) {
     const int l = threadIdx.x & 63;
@@ -574,8 +582,8 @@ __device__ __forceinline__ void role_s_pre(SVars &v, const EnvParams &, SplitMai
             v.a_next++; v.a_chunk++;
             if (v.a_chunk >= p.video_length) { v.a_chunk = 0; v.a_ep++; }
         }
-        // publish: the bytes first, then the counter that vouches for them (read in that order by D)
-        ABR_LDS_ORDER();
+        // publish: the bytes first -- performed, not just issued -- then the counter that vouches for them
+        lds_writes_done();
         if (l == 0) lds_st(&ring.act_hi, v.a_next);
     }
     if (t >= 1 && i < p.n_lanes) service_record(v, p, m2, pb, obs_out, reward_out, done_out);
@@ -625,6 +633,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     // (profiles/r03_ab_split3.txt)
     DVars dv;                          // D's variables stay in registers (every wave sets them up: no value then
     role_d_begin(dv, p);               // depends on the role); P's and S's go through LDS between iterations
+    if (role == 0) ABR_WG_TIME(0);
+    ABR_WG_WHERE(role);
     if (role == 0) __builtin_amdgcn_s_setprio(2);
     else if (role == 1) { __builtin_amdgcn_s_setprio(1); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
     else { SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
@@ -645,9 +655,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         ABR_STAMP(role == 0 ? 5 : (role == 1 ? 18 : 22));
         if (!m.any_alive[t & 1]) break;        // written by P before the barrier: identical in all waves
     }
-    if (role == 0) role_d_end(dv, p);
-    else if (role == 1) { PVars v; p_unpark(park.p, v, p); role_p3_end(v, p); }
-    else { SVars v; s_unpark(park.s, v); role_s_end<MODE>(v, p, m2, obs_out, reward_out, done_out, actions_out, n_total); }
+    if (role == 0) { role_d_end(dv, p); ABR_WG_TIME(1); }
+    else if (role == 1) { PVars v; p_unpark(park.p, v, p); role_p3_end(v, p); ABR_WG_TIME(2); }
+    else { SVars v; s_unpark(park.s, v); role_s_end<MODE>(v, p, m2, obs_out, reward_out, done_out, actions_out, n_total); ABR_WG_TIME(3); }
 }
 
 // =====================================================================================================================

@@ -393,7 +393,7 @@ def test_mpc_previous_bitrate_outside_the_ladder_is_no_decision():
 # ---------------------------------------------------------------------------------------------
 # per-chunk ladders (8f rank 2, build-defined: the reference cannot run a list-MPD)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("impl", ["split3", "split", "jump", "tick"])
+@pytest.mark.parametrize("impl", ["ring3", "split3", "split", "jump", "tick"])
 def test_per_chunk_ladders_against_oracle(oracle, impl, tmp_path):
     import abrsimulator_amd as A
     rng = np.random.default_rng(66)

@@ -35,7 +35,7 @@ def _cmp_step(f64, g, s, name):
     assert np.array_equal((fl >> 2) & 1, g["buffer_full"][:, s])
 
 
-IMPLS = ["split", "split3", "jump", "tick"]   # role-split (2 / 3 waves per 64 lanes), one-thread-per-lane, tick-by-tick cross-check
+IMPLS = ["split", "split3", "ring3", "jump", "tick"]   # role-split (2 / 3 waves per 64 lanes; ring3: three waves coupled by LDS rings), one-thread-per-lane, tick-by-tick cross-check
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -357,7 +357,7 @@ def test_per_lane_speeds(oracle):
         make_env(dict(meta, speed=torch.from_numpy(speeds)), traces, N, impl="tick")
 
 
-@pytest.mark.parametrize("impl", ["split3", "split", "jump"])
+@pytest.mark.parametrize("impl", ["ring3", "split3", "split", "jump"])
 def test_speed_schedule_matches_reference_golden(impl):
     """8f rank 3, second half: the play speed is re-read at every played chunk
     (Simulator.py:176-177).  The fixture is the reference driven by a scripted speed
@@ -563,12 +563,13 @@ def test_timeouts_are_identical_on_every_implementation():
                 assert torch.equal(f[k][ok], ref[1][k][ok]), (impl, k)
     # fused random rollout: split == jump on a workload where most lanes time out
     outs = []
-    for impl in ("split", "jump"):
+    for impl in ("split", "jump", "ring3", "split3"):
         env = make_env(meta, traces, N, impl=impl, max_ticks=mt, auto_reset=True)
         env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
         outs.append(env.step_random(2 * V, 5))
-    for k in ("obs", "reward", "done", "actions"):
-        assert torch.equal(outs[0][k], outs[1][k]), k
+    for o in outs[1:]:
+        for k in ("obs", "reward", "done", "actions"):
+            assert torch.equal(outs[0][k], o[k]), k
     assert int(((outs[0]["done"][-1] & 2) != 0).sum()) > 20
 
 

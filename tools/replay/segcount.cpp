@@ -3,6 +3,9 @@
 // Used by tools/replay_model.py to price kernel schedules before they are written.
 #include <stdint.h>
 static thread_local int g_seg[3];
+// per step of the last episode replayed: 1 = the next call site was NOT max(completion + 1, avail_tick[chunk + 1]),
+// i.e. buffer_full gated the next download (Simulator.py:144) and a speculating download wave repeats it
+static thread_local int g_gated[4096];
 #define ABR_SEGMENT_HOOK(STOP) (g_seg[STOP]++)
 // how each DOWNLOAD segment ended, in order: 'B' = it spent its whole budget (the rest of a trace interval) without
 // reaching the target and without leaving the binade -- a segment a multi-interval jump could absorb; 'X' = anything else
@@ -43,8 +46,12 @@ extern "C" int seg_episode(double interval, double L, int32_t V, double max_buff
             est_out[step * 2 + 0] = tgt / st0.c;                                           // ticks at the current interval's rate
             est_out[step * 2 + 1] = tgt / (0.5 * (st0.c + st0.bw_next * abrx::kTickDt));   // ... at the mean of two intervals
         }
-        abrx::StepResult sr = abrx::lanej_step(s, t, ladder[actions[step]] * L, actions[step]);
+        const abrx::StepStart st = abrx::lanej_begin_step(s.cur, t, s.k, s.chunk_id);
+        const abrx::Download dd = abrx::lanej_download(s.cur, t, st, s.k, ladder[actions[step]] * L);
+        const int32_t k_spec = (k0 + dd.n_dl > st.avail_next) ? k0 + dd.n_dl : st.avail_next;
+        abrx::StepResult sr = abrx::lanej_after_download(s, t, dd, st.avail_next, actions[step]);
         if (sr.timeout) return -2;
+        if (step < 4096) g_gated[step] = (!sr.ended && s.k != k_spec) ? 1 : 0;
         ge_out[step] = g_seg[0]; le_out[step] = g_seg[1] + g_seg[2];
         ndl_out[step] = s.k - k0;
         // trips of a download loop whose trip is [absorb up to M whole 'B' intervals] + [one segment], M = 1, 2, 3, 255
@@ -59,4 +66,8 @@ extern "C" int seg_episode(double interval, double L, int32_t V, double max_buff
         }
     }
     return 0;
+}
+
+extern "C" void seg_gated(int32_t *out, int32_t V) {
+    for (int i = 0; i < V && i < 4096; i++) out[i] = g_gated[i];
 }
