@@ -35,6 +35,10 @@ struct SplitMail {
     int32_t n_dl[2][64], k_start[2][64], step[2][64], action[2][64], avail_next[2][64], flags[2][64];
     // P -> D, double-buffered by iteration parity
     int32_t fb_step[2][64], fb_k[2][64], fb_chunk[2][64], fb_episode[2][64], fb_alive[2][64];
+    // ... and the player's buffer_level / start_up | buffer_empty << 1 at that call site: what D needs to know EXACTLY where
+    // the download after next starts when buffer_full is in reach (abr_lane_jump.h: lanej_predict_next_call)
+    double fb_buf[2][64];
+    int32_t fb_pf[2][64];
     int32_t any_alive[2];
 };
 // three-wave kernel only: the policy's draws for launch steps [act_hi - 64, act_hi), made ahead by the service wave;
@@ -141,35 +145,15 @@ struct DVars {
     abrx::Cursor cur;
     int32_t snap_j, snap_tpos;                 // cursor before the download just issued
     int32_t d_step, d_k, d_chunk, d_ep, offset0, issued_step, issued_k;
+    int32_t issued_ndl, issued_avail;          // the download just issued took this many ticks; avail_tick of the chunk after it
     bool d_alive, was_alive;
 };
-__device__ __forceinline__ void d_park(uint32_t (*area)[64], const DVars &v) {
-    ParkWords k; k.n = 0;
-    pw_i32(k, v.cur.j); pw_i32(k, v.cur.tpos); pw_i32(k, v.cur.tlen); pw_i64(k, (long long)v.cur.trace);
-    pw_i32(k, v.snap_j); pw_i32(k, v.snap_tpos); pw_i32(k, v.d_step); pw_i32(k, v.d_k); pw_i32(k, v.d_chunk);
-    pw_i32(k, v.d_ep); pw_i32(k, v.offset0); pw_i32(k, v.issued_step); pw_i32(k, v.issued_k);
-    pw_i32(k, (v.d_alive ? 1 : 0) | (v.was_alive ? 2 : 0));
-    pw_i32(k, 0);
-    park_store<4>(area, k);
-}
-__device__ __forceinline__ void d_unpark(uint32_t (*area)[64], DVars &v) {
-    ParkWords k; park_load<4>(area, k);
-    int at = 0;
-    v.cur.j = pr_i32(k, at); v.cur.tpos = pr_i32(k, at); v.cur.tlen = pr_i32(k, at);
-    v.cur.trace = (const double *)pr_i64(k, at);
-    v.snap_j = pr_i32(k, at); v.snap_tpos = pr_i32(k, at); v.d_step = pr_i32(k, at); v.d_k = pr_i32(k, at);
-    v.d_chunk = pr_i32(k, at); v.d_ep = pr_i32(k, at); v.offset0 = pr_i32(k, at); v.issued_step = pr_i32(k, at);
-    v.issued_k = pr_i32(k, at);
-    const int32_t fl = pr_i32(k, at);
-    v.d_alive = fl & 1; v.was_alive = fl & 2;
-}
-
 __device__ __forceinline__ void role_d_begin(DVars &v, const EnvParams &p) {
     const int l = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 64 + l;
     v.cur.j = 0; v.cur.tpos = 0; v.cur.tlen = 1; v.cur.trace = p.traces;
     v.snap_j = 0; v.snap_tpos = 0; v.d_step = 0; v.d_k = 0; v.d_chunk = 0; v.d_ep = 0; v.offset0 = 0;
-    v.issued_step = -1; v.issued_k = -1; v.d_alive = false; v.was_alive = false;
+    v.issued_step = -1; v.issued_k = -1; v.issued_ndl = 0; v.issued_avail = 0; v.d_alive = false; v.was_alive = false;
     if (i < p.n_lanes) {
         const int32_t t = p.trace_id[i];
         v.offset0 = p.offset0[i];
@@ -228,7 +212,8 @@ __device__ __forceinline__ void role_d_pre(DVars &v, const EnvParams &p, SplitMa
         m.dl[cb][l] = d.dl; m.n_dl[cb][l] = d.n_dl; m.k_start[cb][l] = v.d_k;
         m.step[cb][l] = v.d_step; m.action[cb][l] = a; m.avail_next[cb][l] = st.avail_next;
         v.issued_step = v.d_step; v.issued_k = v.d_k;
-        // ---- where the NEXT download starts, if nothing gates it ----
+        v.issued_ndl = d.hit ? d.n_dl : 0; v.issued_avail = st.avail_next;
+        // ---- where the NEXT download starts, if nothing gates it (role_d_validate settles the rest) ----
         if (!d.hit) v.d_alive = false;           // bad action or max_ticks: the player retires the lane
         else {
             v.d_step++;
@@ -251,7 +236,7 @@ __device__ __forceinline__ void role_d_pre(DVars &v, const EnvParams &p, SplitMa
 
 // Validate the record issued in iteration t against the player's true call site, which P published before that
 // iteration's barrier (slot t & 1 stays intact until P's iteration t + 2): first thing in iteration t + 1.
-__device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, int32_t t) {
+__device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, const abrx::Tables &tb, int32_t t) {
     const int l = threadIdx.x & 63;
     const int cb = t & 1;
     if (!m.fb_alive[cb][l]) v.d_alive = false;
@@ -263,6 +248,21 @@ __device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, int32_t 
         v.d_chunk = m.fb_chunk[cb][l]; v.d_ep = m.fb_episode[cb][l];
         if (v.issued_step == v.d_step) { v.cur.j = v.snap_j; v.cur.tpos = v.snap_tpos; }
         v.issued_step = -1;
+    } else if (v.d_alive && v.issued_ndl > 0 && v.d_chunk > 0) {
+        // The record issued in iteration t started where the player really was, and the player's buffer at that call site is
+        // known now: if buffer_full is in reach at the completing tick, compute EXACTLY where the next download -- the one
+        // this iteration is about to start -- begins, instead of speculating "not gated" and repeating it.  (A lane whose
+        // buffer sits at max_buffer is gated at almost every decision; round 5: one such lane made its workgroup, and with
+        // it the whole launch, 30 % longer.  d_chunk > 0: not across an episode end, whose first call site is never gated.)
+        const int32_t pf = m.fb_pf[cb][l];
+        const double buf = m.fb_buf[cb][l];
+        if (abrx::lanej_gate_possible(buf, pf & 1, pf & 2, v.issued_ndl, tb)) {
+            int32_t kn;
+            if (abrx::lanej_predict_next_call(buf, v.issued_k, v.issued_ndl, v.issued_avail, tb, kn)) {
+                v.d_k = kn;
+                if (kn >= tb.max_ticks) v.d_alive = false;
+            }
+        }
     }
 }
 
@@ -326,6 +326,7 @@ __device__ __forceinline__ void player_feedback(SplitMail &m, const PVars &v, in
     const bool more = v.b_alive && v.b_step < n_total;
     m.fb_step[cb][l] = v.b_step; m.fb_k[cb][l] = v.s.k; m.fb_chunk[cb][l] = v.s.chunk_id;
     m.fb_episode[cb][l] = v.episode_no; m.fb_alive[cb][l] = more ? 1 : 0;
+    m.fb_buf[cb][l] = v.s.buf; m.fb_pf[cb][l] = (v.s.su ? 1 : 0) | (v.s.be ? 2 : 0);
     const bool any = __any(more) != 0;
     if (l == 0) m.any_alive[cb] = any ? 1 : 0;
 }
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     else { SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {
-            if (t > 0) role_d_validate(dv, m, t - 1);      // against what P published before the previous barrier
+            if (t > 0) role_d_validate(dv, m, make_tables(p), t - 1);      // against what P published before the previous barrier
             role_d_pre<MODE, true>(dv, p, m, &ring, actions, actions_out, n_total, seed, t);
         } else if (role == 1) {
             PVars v; p_unpark(park.p, v, p);
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     else { P2Vars v; role_p2_begin(v, p); p2_park(park.p, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {
-            if (t > 0) role_d_validate(dv, m, t - 1);
+            if (t > 0) role_d_validate(dv, m, make_tables(p), t - 1);
             role_d_pre<MODE, false>(dv, p, m, nullptr, actions, actions_out, n_total, seed, t);
         } else {
             P2Vars v; p2_unpark(park.p, v, fresh_params());

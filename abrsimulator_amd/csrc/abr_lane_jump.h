@@ -496,6 +496,57 @@ ABR_HD StepResult lanej_after_download(LaneJ &s, const Tables &t, const Download
     return r;
 }
 
+// Where the NEXT download of a lane starts, from the player's state at THIS download's call site (buffer_level and the
+// start_up / buffer_empty flags at tick k) and the download's length -- for the download side of the role-split kernels,
+// which otherwise speculates "max(completing tick + 1, avail_next): not gated by buffer_full" (Simulator.py:143-145) and
+// repeats the download when the player says otherwise.  A lane whose buffer sits near max_buffer is gated at almost every
+// decision, and a workgroup is as slow as its slowest lane (round 5: ONE such lane made its workgroup, and with it the whole
+// launch, 30 % longer).  Covers the steady playing state at one play speed for all lanes -- the only state in which
+// buffer_level can reach max_buffer -- by running exactly what lanej_after_download and lanej_wait_call do to
+// (buffer_level, buffer_full, k): the same chains on the same values, hence the same tick.  Returns false when the state is
+// not covered (start-up, empty buffer, the buffer running dry, max_ticks in reach, per-lane speeds): the caller keeps its
+// speculation, and the player's validation of the download's start tick stays the arbiter either way.
+ABR_HD bool lanej_gate_possible(double buf, bool su, bool be, int32_t n_dl, const Tables &t) {
+    // buffer_full at the completing tick needs buffer_level - (n_dl - 1) * sd + L - sd >= max_buffer; real arithmetic with a
+    // margin far above the chains' rounding (<= 1e-9 over an episode), far below one tick's sd
+    return !su && !be && !t.per_lane_speed && (buf + t.L) - (double)n_dl * t.sd >= t.max_buffer - 1.0e-6;
+}
+ABR_HD bool lanej_predict_next_call(double buf, int32_t k, int32_t n_dl, int32_t avail_next, const Tables &t,
+                                    int32_t &k_next) {
+    const int32_t mt = t.max_ticks;
+    double b = buf;
+    int32_t a = 0;
+    // the ticks before the completing one (lanej_idle, playing branch)
+    if (n_dl > 1 && drain_to_zero(b, t.sd, n_dl - 1, a)) return false;
+    // the completing tick (lanej_after_download): :170, :184, :190, :194
+    b = b + t.L;
+    b = b - t.sd;
+    if (b <= 0.0) return false;
+    bool bf = b >= t.max_buffer;
+    k += n_dl;
+    if (k >= mt) return false;
+    // lanej_wait_call
+    if (!(k >= avail_next && !bf)) {
+        int32_t w = avail_next - k;
+        if (w < 0) w = 0;
+        if (w > mt - k) w = mt - k;
+        if (w > 0) {
+            if (drain_to_zero(b, t.sd, w, a)) return false;
+            bf = b >= t.max_buffer;
+            k += w;
+        }
+        if (k >= mt) return false;
+        if (bf) {
+            a = 0;
+            if (!chain<STOP_LT>(b, -t.sd, t.max_buffer, mt - k, a)) return false;
+            k += a;
+            if (b <= 0.0) return false;
+        }
+    }
+    k_next = k;
+    return true;
+}
+
 // One decision in one thread, after lanej_begin_step: download a chunk of target_size, then
 // run to the next call site.
 ABR_HD StepResult lanej_download_and_wait(LaneJ &s, const Tables &t, const StepStart &st,

@@ -22,6 +22,11 @@ Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchron
 sides, max over ranks.  When K < --min-timed-steps that region is repeated (`repeats`) and the
 median repeat is reported, every repeat bracketed the same way.
 
+At N = 1 the default run then adds, in the same JSON line: `selfcheck` (sampled lanes of the LAST TIMED launch replayed
+through the C oracle: observation rows, rewards, done; a mismatch fails the run), `sustained` (>= 1 s of back-to-back
+launches of the same shape in one bracket), `secondary` (MPC combos/s), `mpc_rollout` (abr_env_step_mpc on configs[2]
+and on configs[4]'s per-rank shape) and `strong_1048576`.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline`
 (dominant kernel, HIP-event timed inside the timed region; `binding` = what limits it, from
 the committed SQ counters of the same kernel / lanes / fuse) and `cpu_baseline` (the C oracle
@@ -127,6 +132,59 @@ def cpu_baseline_env(traces, seed, budget_s=12.0):
     return out
 
 
+def selfcheck_env(sc, traces, lane0, seed):
+    """Replays the sampled lanes of the LAST TIMED launch through the C oracle and compares every observation row,
+    reward and done byte that launch wrote for them (float32 of the oracle's float64 value, `==`).  The launch covers
+    decisions [n0, n0 + f) since the reset; all lanes run V-decision episodes in lock-step under auto_reset, so
+    decision n is chunk n % V of episode n // V, whose actions are the counter-based policy's (the launch wrote no
+    action buffer: the oracle.philox_action twin supplies them -- a wrong device action would show in every row)."""
+    from oracle import oracle as O
+    pick, n0, f = sc["pick"], sc["n0"], sc["f"]
+    tid, off = lane_assignment(lane0, int(pick.max()) + 1, traces)
+    tid, off = tid[pick], off[pick]
+    cfg = O.env_cfg(LADDER, L, V, MAX_BUFFER, START_UP, INTERVAL, WEIGHTS, 1.0)
+    P = len(pick)
+    bad = total = 0
+    first = None
+    eps = {}
+    for n in range(n0, n0 + f):
+        e, c = divmod(n, V)
+        if e not in eps:
+            acts = np.stack([O.philox_action(seed, lane0 + pick, s_, e, len(LADDER)) for s_ in range(V)], 1).astype(np.int32)
+            steps, bw, fin, _ = O.env_batch(cfg, traces, tid, off, acts)
+            rew = O.step_rewards(steps["rebuffer_time"], steps["start_up_time"], fin["rebuffer_time"], fin["start_up_time"],
+                                 acts, WEIGHTS, ladder=LADDER)
+            eps[e] = (acts, steps, rew)
+        acts, steps, rew = eps[e]
+        r = n - n0
+        if c < V - 1:      # the observation after decision c is the run() frame at call site c + 1
+            q = c + 1
+            want = [steps["chunk_id"][:, q], acts[:, c], steps["last_bandwidth"][:, q], steps["buffer_level"][:, q],
+                    steps["global_time"][:, q], steps["play_time"][:, q], steps["rebuffer_time"][:, q], steps["start_up_time"][:, q]]
+            dn = 0
+        else:              # episode end under auto_reset: the fresh episode's first call site
+            want = [steps["chunk_id"][:, 0], np.full(P, -1), np.zeros(P), steps["buffer_level"][:, 0],
+                    steps["global_time"][:, 0], steps["play_time"][:, 0], steps["rebuffer_time"][:, 0], steps["start_up_time"][:, 0]]
+            dn = 1
+        for row in range(8):
+            m = sc["obs"][r, row] != np.asarray(want[row], np.float64).astype(np.float32)
+            bad += int(m.sum()); total += P
+            if m.any() and first is None:
+                first = f"decision {n} (episode {e}, chunk {c}) obs row {row} lane {int(lane0 + pick[np.argmax(m)])}"
+        m = sc["reward"][r] != rew[:, c]
+        bad += int(m.sum()); total += P
+        if m.any() and first is None:
+            first = f"decision {n} (episode {e}, chunk {c}) reward lane {int(lane0 + pick[np.argmax(m)])}"
+        m = sc["done"][r] != dn
+        bad += int(m.sum()); total += P
+        if m.any() and first is None:
+            first = f"decision {n} (episode {e}, chunk {c}) done lane {int(lane0 + pick[np.argmax(m)])}"
+    return {"lanes": int(P), "decisions": int(f), "first_decision": int(n0), "elements": int(total), "mismatches": int(bad),
+            "first_mismatch": first,
+            "what": "obs rows (8), reward, done of the last timed launch for the sampled lanes == float32(C oracle), "
+                    "incl. the first and last workgroup; actions from the oracle's philox twin"}
+
+
 def cpu_baseline_mpc(budget_s=10.0):
     from concurrent.futures import ThreadPoolExecutor
 
@@ -205,6 +263,10 @@ def main():
                          "repeated (each repeat bracketed by barrier + synchronize) and the MEDIAN repeat "
                          "is reported, so that one sub-millisecond launch is not the whole sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="env_random, N=1: skip the sustained block")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0)
+    ap.add_argument("--no-mpc-rollout", action="store_true",
+                    help="env_random, N=1: skip the mpc_rollout block (BASELINE.json configs[2] composed and configs[4]'s per-rank shape)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="env_random, N=1: skip the MPC combos/s half of BASELINE.json's metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (obs, reward)")
@@ -338,6 +400,7 @@ def main():
                 env_.step_random(F_, a.seed, out=bufs[0])
 
         pool = []      # HIP events are created on their first record(): do that outside the timed region
+        info = dict(n_done=0, last=None, bufs=bufs, slabs=slabs)     # decisions run so far; (buffer, decisions, first decision) of the last launch
 
         def take():
             return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
@@ -355,6 +418,7 @@ def main():
                 if timed:
                     e1 = take(); e1.record()
                     events_.append((e0, e1, F_))
+                info["last"] = (0, F_, info["n_done"]); info["n_done"] += F_
                 left -= F_
             while left > 0:
                 f = min(F_, left)
@@ -369,10 +433,13 @@ def main():
                     events_.append((e0, e1, f))
                 if gather and f == F_:
                     gat_.gather(b, slabs[b][3])
+                info["last"] = (b, f, info["n_done"]) if f == F_ else None
+                info["n_done"] += f
                 left -= f
                 it += 1
             if gather:
                 gat_.finish()
+        run_.info = info
         return run_, gat_
 
     if a.workload == "env_random":
@@ -425,6 +492,50 @@ def main():
 
     avg_launch_s, f_per_launch = launch_stats(ev)
 
+    # ---- self-check, part 1 (N = 1): keep what the LAST TIMED launch wrote for a sample of lanes -- its observation rows,
+    #      rewards and done bytes -- before anything overwrites the slab.  Part 2 replays those lanes through the oracle in
+    #      the cpu_baseline leg below and puts the verdict into the line; a mismatch fails the run. ----
+    selfcheck_in = None
+    if a.workload == "env_random" and world == 1 and not a.no_cpu_baseline and getattr(run, "info", None) and run.info["last"]:
+        b_, f_, n0_ = run.info["last"]
+        rng_ = np.random.default_rng(5)
+        pick = np.unique(np.concatenate([np.arange(8), np.arange(N - 8, N), [63, 64, 127, 128],
+                                         rng_.integers(0, N, 300)])).astype(np.int64)
+        pick = pick[(pick >= 0) & (pick < N)]
+        pk = torch.from_numpy(pick).to(dev)
+        bo = run.info["bufs"][b_]
+        selfcheck_in = dict(pick=pick, n0=n0_, f=f_, obs=bo["obs"][:f_].index_select(2, pk).cpu().numpy(),
+                            reward=bo["reward"][:f_].index_select(1, pk).cpu().numpy(),
+                            done=bo["done"][:f_].index_select(1, pk).cpu().numpy())
+
+    # ---- sustained (N = 1): at least a second of back-to-back launches of the SAME shape in ONE bracket, so that clocks and
+    #      thermals have settled and an outside sampler sees the GPU busy; the headline above stays what it was ----
+    sustained = None
+    if a.workload == "env_random" and world == 1 and not a.no_sustained and getattr(run, "info", None):
+        n_l = int(np.ceil(a.sustained_seconds * 1.1 / max(avg_launch_s, 1e-6)))
+        per_mark = max(1, int(0.1 / max(avg_launch_s, 1e-6)))          # an event every ~100 ms
+        bufs_ = run.info["bufs"]
+        marks = []
+        barrier()
+        t0 = time.perf_counter()
+        for j in range(n_l):
+            if j % per_mark == 0:
+                e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((j, e))
+            env.step_random(F, a.seed, out=bufs_[j & 1])
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((n_l, e))
+        barrier()
+        el_s = time.perf_counter() - t0
+        run.info["n_done"] += n_l * F; run.info["last"] = None
+        win = [(j1 - j0) * F * N / (e0.elapsed_time(e1) * 1e-3) for (j0, e0), (j1, e1) in zip(marks[:-1], marks[1:])
+               if j1 - j0 == per_mark]
+        sustained = {"value": N * F * n_l / el_s, "unit": unit, "seconds": el_s, "launches": n_l, "fuse": F,
+                     "ms_per_step": el_s / (n_l * F) * 1e3,
+                     "first_100ms_value": win[0] if win else None, "last_100ms_value": win[-1] if win else None,
+                     "last_over_first": (win[-1] / win[0]) if len(win) >= 2 else None,
+                     "windows_100ms": len(win), "min_window_value": min(win) if win else None,
+                     "note": "one bracket (barrier + synchronize on both sides) around all launches; the windows are HIP "
+                             "events recorded every ~100 ms inside it"}
+
     def env_roofline():
         # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
         # launch; per decision: obs 32 + reward 4 + done 1 out, previous_bitrates 1 +
@@ -441,6 +552,13 @@ def main():
                          "HBM-bound (SURVEY.md 8d); the HBM fraction is reported as mandated, and "
                          "`binding` names the resource that actually limits it")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["frac_formula"] = ("fused-launch bytes: per decision 32 obs + 4 reward + 1 done + 9 history + 4.07 trace points x 12 "
+                                "= 94.8 B, plus 2 x 94 B of lane state ONCE per launch")
+        # SURVEY.md 8(d) literally: state read + write (2 x 96) + action in 4 + obs/reward/done out 29 + 4 B per trace point
+        # walked, charged PER STEP -- what a one-decision-per-launch kernel moves; a fused launch does not re-read the state
+        survey_bytes = N * f_per_launch * (192 + 4 + 29 + 4 * 4.07)
+        roof["frac_survey_8d"] = survey_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        roof["frac_survey_8d_formula"] = "SURVEY.md 8(d): (192 + 4 + 29 + 4 x points walked) B per step = 241.3 B, state traffic charged per step"
         t = _load_traffic("env_random", env_kernel, N, int(round(f_per_launch)))
         if t:
             roof["traffic"] = t["bytes_per_launch"]
@@ -546,8 +664,65 @@ def main():
                                  f"{gat_s.n_collectives}x" if gat_s else "none")}
         del env_s
 
+    # ---- the MPC-driven rollout (N = 1): BASELINE.json configs[2] composed (65 536 envs x MPC horizon 5, abr_env_step_mpc)
+    #      and configs[4]'s per-rank shape (131 072 lanes of the 1 048 576-lane job, rank 7's lane ids, mixed 300-3 000-point
+    #      traces).  One timed region = ONE 48-decision episode of every lane in one abr_env_step_mpc call; the K3 / K1
+    #      split comes from HIP events around the two halves of a host-loop pass over the same decisions. ----
+    mpc_rollout = None
+    if a.workload == "env_random" and world == 1 and not a.no_mpc_rollout:
+        mpc_rollout = {}
+        for name, lanes_r, mixed_r, base_r in (("configs2_65536", 65536, False, 0),
+                                               ("configs4_rank7_131072_mixed", 131072, True, 7 * 131072)):
+            tr_r = synth_traces(mixed_r)
+            tid_r, off_r = lane_assignment(base_r, lanes_r, tr_r)
+            env_r = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, tr_r), lanes_r, device=dev,
+                                    auto_reset=True, lane_id_base=base_r, impl=a.impl)
+            env_r.reset(torch.from_numpy(tid_r), torch.from_numpy(off_r))
+            ctl_r = A.BatchedMPCController(
+                A.EnvPlayer(env_r, mpd=A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
+                            qoe=A.QOEMetric(4.3, 1.0, 0.0)), horizon=5, clip_horizon=True, device=dev)
+            out_r = dict(obs=torch.empty(V, OBS_DIM, lanes_r, dtype=torch.float32, device=dev),
+                         reward=torch.empty(V, lanes_r, dtype=torch.float32, device=dev),
+                         done=torch.empty(V, lanes_r, dtype=torch.uint8, device=dev),
+                         actions=torch.empty(V, lanes_r, dtype=torch.int32, device=dev))
+
+            def region(n_, _e=env_r, _c=ctl_r, _o=out_r):
+                _e.step_mpc(_c, n_, out=_o)
+            region(V)                                            # one episode of warm-up
+            times_r = []
+            for _ in range(5):
+                barrier(); t0 = time.perf_counter(); region(V); barrier()
+                times_r.append(time.perf_counter() - t0)
+            el_r = float(np.median(times_r))
+            ends = int(out_r["done"][-1].sum().item())           # every lane ends its episode at the last decision
+            # the split: the same decisions as select + step from the host, HIP events around each half
+            evs = []
+            for _ in range(V):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e2 = torch.cuda.Event(enable_timing=True)
+                e0.record(); act = ctl_r.next_bitrate(); e1.record()
+                env_r.step(torch.clamp(act, min=0))      # D13 at chunk 0: "no decision" -> rate 0, as the fused call does
+                e2.record()
+                evs.append((e0, e1, e2))
+            torch.cuda.synchronize(dev)
+            k3 = float(np.mean([x.elapsed_time(y) for x, y, _ in evs])) * 1e3
+            k1 = float(np.mean([y.elapsed_time(z) for _, y, z in evs])) * 1e3
+            mpc_rollout[name] = {
+                "metric": "env_steps_per_sec_mpc_policy", "value": lanes_r * V / el_r, "unit": "env-steps/s",
+                "combos_per_sec": lanes_r * V * 6 ** 5 / el_r, "lanes": lanes_r, "lane_id_base": base_r,
+                "decisions_per_region": V, "us_per_decision": el_r / V * 1e6, "repeats": len(times_r), "repeat_seconds": times_r,
+                "traces": f"{N_TRACES} x " + ("300..3000" if mixed_r else str(TRACE_LEN)),
+                "episodes_ended_at_last_decision": ends, "call": "abr_env_step_mpc(n_steps=48): K3 + K1 per decision, no host work between",
+                "split_host_loop": {"k3_select_us": k3, "k1_step_us": k1, "k1_impl": env_r.effective_impl(fused=False),
+                                    "note": "HIP events around next_bitrate() and step() of a host loop over one more episode"}}
+            del env_r, ctl_r, out_r
+            torch.cuda.empty_cache()
+
     cpu = None
+    selfcheck = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if selfcheck_in is not None:
+            selfcheck = selfcheck_env(selfcheck_in, traces, lane0, a.seed)
         cpu = cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(traces, a.seed)
         if secondary is not None:
             secondary["cpu_baseline"] = cpu_baseline_mpc(budget_s=5.0)
@@ -575,6 +750,12 @@ def main():
                                       f"{gat.n_collectives if gat else 0}x" if gathering else "none")},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if selfcheck is not None:
+            line["selfcheck"] = selfcheck
+        if sustained is not None:
+            line["sustained"] = sustained
+        if mpc_rollout is not None:
+            line["mpc_rollout"] = mpc_rollout
         if control is not None:
             line["control"] = control
         if secondary is not None:
@@ -584,6 +765,9 @@ def main():
         print(json.dumps(line))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0 and selfcheck is not None and selfcheck["mismatches"]:
+        raise SystemExit(f"bench.py self-check FAILED: {selfcheck['mismatches']} of {selfcheck['elements']} elements of the timed "
+                         f"launch differ from the oracle; first: {selfcheck['first_mismatch']}")
 
 
 if __name__ == "__main__":

@@ -294,3 +294,36 @@ def philox_action(seed, lane, step, episode, n_rates):
         k0 = (k0 + np.uint64(0x9E3779B9)) & M
         k1 = (k1 + np.uint64(0xBB67AE85)) & M
     return ((c0 * np.uint64(n_rates)) >> np.uint64(32)).astype(np.int32)
+
+
+def step_rewards(rebuffer_time, start_up_time, final_rebuffer_time, final_start_up_time, actions,
+                 weights, ladder=None, br_table=None, dtype=np.float32):
+    """Per-step linear QoE reward derived from REFERENCE quantities, float32 [N, V].
+
+    calculate_qoe (Simulator.py:79-86) split at the ABR call sites (:155) with the timers of :137-140:
+        r_s = wr * (rebuffer_time[s+1] - rebuffer_time[s]) + ws * (start_up_time[s+1] - start_up_time[s])
+              + wv * |br[s][a_s] - br[s-1][a_(s-1)]|
+    where index s is the s-th call site's run() frame, s = 0 takes its deltas from 0 (the time before the
+    first call site belongs to the first decision) and has no variance term, and the last step takes
+    the frame calculate_qoe was called from (final_*).  br[s] is the single ladder, or chunk s's own row
+    of a per-chunk table.  Inputs are the goldens' / the oracle's float64 arrays [N, V] and [N]; the
+    operation order is the kernels' ((wr*d_rb + ws*d_su) + wv*var in float64, then one rounding to
+    float32), so the comparison is `==`."""
+    rb = np.asarray(rebuffer_time, np.float64)
+    su = np.asarray(start_up_time, np.float64)
+    a = np.asarray(actions)
+    N, V = a.shape
+    wr, wv, ws = float(weights[0]), float(weights[1]), float(weights[2])
+    rb_next = np.concatenate([rb[:, 1:], np.asarray(final_rebuffer_time, np.float64)[:, None]], 1)
+    su_next = np.concatenate([su[:, 1:], np.asarray(final_start_up_time, np.float64)[:, None]], 1)
+    rb_prev = np.concatenate([np.zeros((N, 1)), rb[:, 1:]], 1)
+    su_prev = np.concatenate([np.zeros((N, 1)), su[:, 1:]], 1)
+    if br_table is not None:
+        tab = np.asarray(br_table, np.float64)                       # [V][B]
+        br = tab[np.arange(V)[None, :], a]                           # br[s][a_s]
+    else:
+        br = np.asarray(ladder, np.float64)[a]
+    var = np.zeros((N, V))
+    var[:, 1:] = np.abs(br[:, 1:] - br[:, :-1])
+    r = (wr * (rb_next - rb_prev) + ws * (su_next - su_prev)) + wv * var
+    return r.astype(dtype)

@@ -13,7 +13,15 @@ struct Ctx {
     int n_rates;
 };
 
+// lanej_predict_next_call against what the lane really does: [0] decisions, [1] of them gated by buffer_full (the next call
+// site is not max(completing tick + 1, avail_next)), [2] gated ones the predictor covered, [3] predictions made, [4] wrong ones
+static long long g_pred[5];
+
 extern "C" {
+
+void lj_predict_stats(long long *out, int reset) {
+    for (int i = 0; i < 5; i++) { out[i] = g_pred[i]; if (reset) g_pred[i] = 0; }
+}
 
 void *lj_create(double interval, double L, double speed, int32_t V, double max_buffer,
                 double start_up_length, int32_t max_ticks, const double *ladder, int32_t n_rates) {
@@ -59,8 +67,25 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
         r[4] = s.buf; r[5] = last_bw; r[6] = (double)s.sumk;
         r[7] = (double)((s.su ? 1 : 0) | (s.be ? 2 : 0) | (s.bf ? 4 : 0));
         int a = actions[step];
-        abrx::StepResult sr = abrx::lanej_step(s, t, c->ladder[a] * t.L, a);
+        // the step in its two halves, as the role-split kernels run it, with the download side's call-site prediction
+        const double buf0 = s.buf; const bool su0 = s.su, be0 = s.be; const int32_t k0 = s.k;
+        const abrx::StepStart st = abrx::lanej_begin_step(s.cur, t, s.k, s.chunk_id);
+        const abrx::Download dd = abrx::lanej_download(s.cur, t, st, s.k, c->ladder[a] * t.L);
+        abrx::StepResult sr = abrx::lanej_after_download(s, t, dd, st.avail_next, a);
         if (sr.timeout) return -2;
+        if (!sr.ended && dd.hit) {
+            const int32_t spec = k0 + dd.n_dl > st.avail_next ? k0 + dd.n_dl : st.avail_next;
+            const bool gated = s.k != spec;
+            g_pred[0]++; g_pred[1] += gated ? 1 : 0;
+            int32_t kn = -1;
+            const bool poss = abrx::lanej_gate_possible(buf0, su0, be0, dd.n_dl, t);
+            if (gated && !poss && !t.per_lane_speed && !su0 && !be0) return -8;   // the cheap test must not miss a gated step of a playing lane
+            if (poss && abrx::lanej_predict_next_call(buf0, k0, dd.n_dl, st.avail_next, t, kn)) {
+                g_pred[3]++;
+                if (gated) g_pred[2]++;
+                if (kn != s.k) { g_pred[4]++; return -7; }
+            }
+        }
         last_bw = sr.bw;
         bw_out[step] = sr.bw;
         if (sr.ended != (step == t.V - 1)) return -5;

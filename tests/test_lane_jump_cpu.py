@@ -220,3 +220,27 @@ def test_speed_schedule_against_oracle(H, oracle, seed):
         assert np.array_equal(fin[:, c], fino[k]), k
     assert np.array_equal(bw, bwo)
     assert np.array_equal(fin_i[:, 1], fino["play_id"])
+
+
+def test_call_site_prediction_of_the_download_side(H, oracle):
+    """lanej_predict_next_call (round 5): the download side's exact prediction of the next call site for lanes whose
+    buffer sits at max_buffer (buffer_full gates almost every decision, Simulator.py:143-145).  The harness runs it at
+    EVERY decision of every episode above and returns an error on a wrong tick or on a gated step of a playing lane
+    that the cheap test misses; here: workloads in which gating is frequent, and the coverage numbers."""
+    stats = (C.c_longlong * 5)()
+    H.lj_predict_stats(stats, 1)
+    for kw in (dict(seed=31, N=800, V=48, max_buffer=20.0, bw=(3.0, 6.0), ladder=(0.3, 0.75, 1.2, 1.85, 2.85, 4.3)),
+               dict(seed=32, N=800, V=24, L=2.0, max_buffer=6.0, start_up=2.0, interval=0.3, bw=(1.0, 8.0)),
+               dict(seed=33, N=800, V=24, L=3.0, max_buffer=9.0, start_up=3.0, interval=0.05, speed=1.25, bw=(2.0, 9.0)),
+               dict(seed=34, N=800, V=16, ragged=True, max_buffer=8.0, start_up=8.0, bw=(0.2, 6.0))):
+        meta, traces, trace_id, offset, actions = _case(**kw)
+        cfg = oracle.env_cfg(meta["ladder"], meta["chunk_length"], meta["video_length"], meta["max_buffer"],
+                             meta["start_up_length"], meta["interval"], meta["weights"], meta["speed"])
+        steps, bwo, fino, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions)
+        rec, bw, fin, fin_i = run_jump(H, meta, traces, trace_id, offset, actions)      # raises on a wrong prediction
+        _check(rec, bw, fin, steps, bwo, fino)
+    H.lj_predict_stats(stats, 0)
+    decisions, gated, covered, made, wrong = list(stats)
+    assert wrong == 0
+    # made > gated: buffer_full at the completing tick that the wait for availability clears again; uncovered: gated out of start-up
+    assert gated > 2000 and made >= covered > 0.9 * gated, list(stats)
