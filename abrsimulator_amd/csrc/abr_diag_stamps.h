@@ -38,7 +38,7 @@ __shared__ unsigned long long g_sh_st[3][33];
     } while (0)
 // when each role of each workgroup began and ended (s_memtime): [workgroup][0 = begin, 1 = D end, 2 = P end, 3 = S end]
 // [4 + role]: where that role's wave ran: HW_REG_XCC_ID << 16 | HW_REG_HW_ID (simd_id[5:4] cu_id[11:8] sh_id[12] se_id[15:13])
-__device__ unsigned long long g_wg_t[4096][8];
+__device__ unsigned long long g_wg_t[4096][10];    // [8], [9]: begin / S end on the constant 100 MHz clock (s_memrealtime)
 #define ABR_WG_WHERE(role)                                                                     \
     do {                                                                                       \
         unsigned hw_, xcc_;                                                                    \
@@ -51,6 +51,8 @@ __device__ unsigned long long g_wg_t[4096][8];
     do {                                                                                       \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                      \
             g_wg_t[blockIdx.x][slot] = (unsigned long long)__builtin_amdgcn_s_memtime();       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && ((slot) == 0 || (slot) == 3))     \
+            g_wg_t[blockIdx.x][(slot) == 0 ? 8 : 9] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); \
     } while (0)
 // K3: cycles per phase, lane 0 of every wave; kept in registers, added to the global accumulators (slots 26..30) at the end
 #define K3_STAMP_DECL long long k3_t_ = __builtin_amdgcn_s_memtime(); long long k3_d_[5] = {0, 0, 0, 0, 0};

@@ -1228,7 +1228,7 @@ extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
 #ifdef ABR_SPLIT_STAMPS
 extern "C" int abr_debug_read_wg_times(unsigned long long *out, int n_wg) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), (size_t)n_wg * 8 * sizeof(unsigned long long));
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), (size_t)n_wg * 10 * sizeof(unsigned long long));
     return 0;
 }
 #endif

@@ -29,6 +29,15 @@
 #ifndef ABR_ENV_ROLES_H
 #define ABR_ENV_ROLES_H
 
+// Outputs (observations, rewards, done bytes, the history rows) are written once and never read by the launch that writes
+// them: non-temporal stores, so that they do not evict the tick tables and traces from the XCD's L2 (+1.0 % at fuse 48,
+// +0.5 % at fuse 20, same-box A/B: profiles/r05_ab_nt_stores.txt; -DABR_NO_NT_STORES builds the plain form).
+#ifndef ABR_NO_NT_STORES
+#define ABR_OUT(ref, val) __builtin_nontemporal_store((val), &(ref))
+#else
+#define ABR_OUT(ref, val) ((ref) = (val))
+#endif
+
 struct SplitMail {
     // D -> P, double-buffered by iteration parity
     double dl[2][64];
@@ -454,14 +463,14 @@ __device__ __forceinline__ void s_unpark(uint32_t (*area)[64], SVars &v) {
 __device__ __forceinline__ void service_write_obs(const SVars &v, const EnvParams &p, int64_t i, float *obs) {
     if (!obs) return;
     const int64_t n = p.n_lanes;
-    obs[ABR_OBS_CHUNK_ID * n + i] = (float)v.o_chunk;
-    obs[ABR_OBS_LAST_BITRATE * n + i] = (float)v.o_last;
-    obs[ABR_OBS_LAST_BANDWIDTH * n + i] = (float)v.last_bw;
-    obs[ABR_OBS_BUFFER_LEVEL * n + i] = (float)v.o_buf;
-    obs[ABR_OBS_GLOBAL_TIME * n + i] = (float)p.G[v.o_k];
-    obs[ABR_OBS_PLAY_TIME * n + i] = (float)(p.lane_speeds ? v.o_pt : p.GP[v.o_nplay]);
-    obs[ABR_OBS_REBUFFER_TIME * n + i] = (float)p.G[v.o_nrb];
-    obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[v.o_nsu];
+    ABR_OUT(obs[ABR_OBS_CHUNK_ID * n + i], (float)v.o_chunk);
+    ABR_OUT(obs[ABR_OBS_LAST_BITRATE * n + i], (float)v.o_last);
+    ABR_OUT(obs[ABR_OBS_LAST_BANDWIDTH * n + i], (float)v.last_bw);
+    ABR_OUT(obs[ABR_OBS_BUFFER_LEVEL * n + i], (float)v.o_buf);
+    ABR_OUT(obs[ABR_OBS_GLOBAL_TIME * n + i], (float)p.G[v.o_k]);
+    ABR_OUT(obs[ABR_OBS_PLAY_TIME * n + i], (float)(p.lane_speeds ? v.o_pt : p.GP[v.o_nplay]));
+    ABR_OUT(obs[ABR_OBS_REBUFFER_TIME * n + i], (float)p.G[v.o_nrb]);
+    ABR_OUT(obs[ABR_OBS_STARTUP_TIME * n + i], (float)p.G[v.o_nsu]);
 }
 
 // the record P left in slot `sl`: division, history, reward, done, observation, episode end
@@ -481,8 +490,8 @@ __device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 
     v.s_next = step + 1;
     if (m2m & kS3Bad) {
         v.done |= ABR_DONE_BADACT;
-        if (reward_out) reward_out[o] = 0.0f;
-        if (done_out) done_out[o] = v.done;
+        if (reward_out) ABR_OUT(reward_out[o], 0.0f);
+        if (done_out) ABR_OUT(done_out[o], v.done);
         service_write_obs(v, p, i, obs);
         return;
     }
@@ -492,8 +501,8 @@ __device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 
     if (m2m & kS3Hit) {
         const double bw = m2.dl[sl][l] / p.G[m2.n_dl[sl][l]];                  // :164
         const int64_t h = (int64_t)chunk * p.n_lanes + i;
-        p.bw_hist[h] = bw;
-        p.action_hist[h] = (uint8_t)a;                                       // :165
+        ABR_OUT(p.bw_hist[h], bw);
+        ABR_OUT(p.action_hist[h], (uint8_t)a);                                       // :165
         v.last_bw = bw;
         v.hist_s = v.hist_s + 1.0 / bw;     // sum(1/x), list order (mpc.py:86-88)
         v.hist_n = v.hist_n + 1.0;
@@ -506,8 +515,8 @@ __device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 
     const double rew = p.wr * (g_rb - v.g_rb_obs) + p.ws * (g_su - v.g_su_obs) + p.wv * var;
     if (m2m & kS3Ended) v.done |= ABR_DONE_EPISODE;
     if (m2m & kS3Timeout) v.done |= ABR_DONE_TIMEOUT;
-    if (reward_out) reward_out[o] = (float)rew;
-    if (done_out) done_out[o] = v.done;
+    if (reward_out) ABR_OUT(reward_out[o], (float)rew);
+    if (done_out) ABR_OUT(done_out[o], v.done);
     v.n_su_obs = nsu_r; v.n_rb_obs = nrb_r; v.g_su_obs = g_su; v.g_rb_obs = g_rb;
     if (m2m & (kS3Ended | kS3Timeout)) {
         p.ep_qoe_terms[0 * p.n_lanes + i] = g_rb;

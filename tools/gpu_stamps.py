@@ -48,10 +48,10 @@ for k in sorted(regions):
 # different base per XCD, so only differences inside a workgroup mean anything.
 if hasattr(env.lib, "abr_debug_read_wg_times"):
     nw = min(waves, 4096)
-    wt = (C.c_ulonglong * (nw * 8))()
+    wt = (C.c_ulonglong * (nw * 10))()
     env.lib.abr_debug_read_wg_times.argtypes = [C.c_void_p, C.c_int]
     env.lib.abr_debug_read_wg_times(wt, nw)
-    w = np.array(wt, dtype=np.uint64).reshape(nw, 8)
+    w = np.array(wt, dtype=np.uint64).reshape(nw, 10)
     t = w[:, :4].astype(np.float64)
     life = t[:, 3] - t[:, 0]
     print(f"  workgroup lifetime (D begin -> S end): mean {life.mean():.0f}  p05 {np.percentile(life, 5):.0f}  p50 {np.percentile(life, 50):.0f}  "
@@ -75,6 +75,14 @@ if hasattr(env.lib, "abr_debug_read_wg_times"):
     for g in worst:
         print(f"  slowest: workgroup {g:5d} lifetime {life[g]:9.0f}  D/P/S waves alone-of-their-role on their SIMD: "
               + " ".join(f"{name}:{per[r][int(simd[g, r])]}/{tot[int(simd[g, r])]}" for r, name in enumerate("DPS")))
+    # the same on the constant 100 MHz clock (s_memrealtime): wall time, comparable across XCDs
+    rt = (w[:, 9].astype(np.float64) - w[:, 8].astype(np.float64)) * 0.01      # microseconds
+    rt0 = (w[:, 8].astype(np.float64) - w[:, 8].astype(np.float64).min()) * 0.01
+    end = rt0 + rt
+    print(f"  wall time (s_memrealtime): workgroup lifetime mean {rt.mean():.1f} us  p05 {np.percentile(rt, 5):.1f}  p95 {np.percentile(rt, 95):.1f}  max {rt.max():.1f};  "
+          f"begin spread {rt0.max():.1f} us;  last workgroup ends {end.max():.1f} us after the first began (mean end {end.mean():.1f})")
+    xq = (w[:, 4] >> np.uint64(16)).astype(np.int64)
+    print("  wall lifetime / shader cycles by XCD:", "  ".join(f"{x}: {rt[xq == x].mean():.1f} us, {life[xq == x].mean() / rt[xq == x].mean() / 1000:.3f} GHz" for x in sorted(set(xq.tolist()))))
     # ... and by where the workgroup ran
     cu = ((w[:, 4] >> np.uint64(16)) << np.uint64(16)) | (w[:, 4] & np.uint64(0xff00))       # xcc, se, sh, cu of the D wave
     xcc = (w[:, 4] >> np.uint64(16)).astype(np.int64)
