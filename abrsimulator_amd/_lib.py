@@ -13,12 +13,26 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libabr_hip.so")
-if os.environ.get("ABR_HIP_LIB"):          # diagnostic builds of the same ABI (csrc/Makefile)
-    SO_PATH = os.path.join(CSRC, os.environ["ABR_HIP_LIB"])
-ASYNC_SO = "libabr_hip_async.so"           # diagnostic: the product + the asynchronous pipeline (impl 4)
+# diagnostic builds of the same ABI (rejected kernels, instrumentation) live OUTSIDE the package: tools/diag/csrc builds them
+# into tools/diag/lib.  The package never loads one by itself: ABR_HIP_LIB / BatchedABREnv(library=...) name them explicitly.
+DIAG_LIB_DIR = os.path.join(os.path.dirname(_HERE), "tools", "diag", "lib")
 
-ABI_VERSION = 2
+
+def resolve(name):
+    """Path of a library given by name: a path as it is; a bare file name in tools/diag/lib, then in csrc/."""
+    if os.sep in name or os.path.isabs(name):
+        return os.path.abspath(name)
+    for d in (DIAG_LIB_DIR, CSRC):
+        if os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return os.path.join(DIAG_LIB_DIR, name)
+
+
+SO_PATH = os.path.join(CSRC, "libabr_hip.so")
+if os.environ.get("ABR_HIP_LIB"):          # run everything on a diagnostic build (tools/, A/B scripts)
+    SO_PATH = resolve(os.environ["ABR_HIP_LIB"])
+
+ABI_VERSION = 3
 MAX_RATES = 16
 MAX_HORIZON = 8
 OBS_DIM = 8
@@ -74,6 +88,7 @@ SYMBOLS = [
     ("abr_env_destroy", C.c_int, [_P]),
     ("abr_env_set_lane_id_base", C.c_int, [_P, C.c_int64]),
     ("abr_env_set_impl", C.c_int, [_P, C.c_int32]),
+    ("abr_env_has_impl", C.c_int, [C.c_int32]),
     ("abr_env_set_lane_speeds", C.c_int, [_P, _P]),
     ("abr_env_set_bitrate_table", C.c_int, [_P, _P]),
     ("abr_env_set_speed_schedule", C.c_int, [_P, _P, C.c_int32]),
@@ -113,8 +128,8 @@ def build(force=False, target="libabr_hip.so"):
 
 def lib(name=None):
     """The loaded C-ABI library.  Raises ImportError if it is absent -- by design.  `name`: a
-    diagnostic build of the same ABI in csrc/ (csrc/Makefile), e.g. ASYNC_SO; default: the product."""
-    path = os.path.join(CSRC, name) if name else SO_PATH
+    diagnostic build of the same ABI (tools/diag/csrc/Makefile), by path or file name; default: the product."""
+    path = resolve(name) if name else SO_PATH
     L = _libs.get(path)
     if L is None:
         if not os.path.exists(path):

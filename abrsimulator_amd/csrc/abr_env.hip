@@ -35,7 +35,20 @@
 
 #include "abr_env.h"
 
-#include "abr_diag_stamps.h"   // cycle stamps: no-ops unless built with -DABR_SPLIT_STAMPS (libabr_hip_stamps.so)
+// Cycle stamps and per-workgroup timing exist only in the diagnostic build (tools/diag/csrc: -DABR_SPLIT_STAMPS); the
+// product compiles them to nothing.
+#ifdef ABR_SPLIT_STAMPS
+#include "abr_diag_stamps.h"
+#else
+#define ABR_STAMP(n)
+#define ABR_STAMP_INIT()
+#define ABR_STAMP_FLUSH()
+#define ABR_WG_TIME(slot)
+#define ABR_WG_WHERE(role)
+#define K3_STAMP_DECL
+#define K3_STAMP(n)
+#define K3_STAMP_FLUSH()
+#endif
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
@@ -592,9 +605,12 @@ __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i
 #ifndef ABR_JUMP_WAVES
 #define ABR_JUMP_WAVES 5
 #endif
-#define ABR_JUMP_BOUNDS __launch_bounds__(64, ABR_JUMP_WAVES)
+// MODE 1 (ONE decision per launch: abr_env_step, the K1 launches of abr_env_step_mpc -- what `auto` runs at every size) is
+// compiled for four waves: a single pass through a decision gains nothing from the fifth wave, and the 102-VGPR bound
+// cost it 12 B of scratch per lane (round 5).
+#define ABR_JUMP_BOUNDS(MODE) __launch_bounds__(64, ((MODE) == 1 ? 4 : ABR_JUMP_WAVES))
 template <int MODE>
-__global__ ABR_JUMP_BOUNDS void env_jump_kernel(
+__global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
     EnvParams p, const int32_t *__restrict__ actions, const int32_t *__restrict__ trace_id_in,
     const int32_t *__restrict__ offset_in, const uint8_t *__restrict__ lane_mask,
     float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
@@ -731,9 +747,12 @@ __global__ ABR_JUMP_BOUNDS void env_jump_kernel(
 }
 
 #include "abr_env_roles.h"     // K1, role-split form: env_split3_kernel (three waves per 64 lanes), env_split_kernel (two)
-#include "abr_env_ring.h"      // K1, role-split form without a per-iteration barrier: env_ring3_kernel (round 5)
+// Diagnostic builds only (tools/diag/csrc; `auto` never picks them, the product library does not contain them):
+#ifdef ABR_WITH_RING
+#include "abr_env_ring.h"      // the role pipeline coupled by LDS rings instead of a per-iteration barrier (round 5, impl 6)
+#endif
 #ifdef ABR_WITH_ASYNC
-#include "abr_env_async.h"      // diagnostic build only (libabr_hip_async.so): the asynchronous pipeline `auto` never picks
+#include "abr_env_async.h"     // the asynchronous pipeline of round 3 (impl 4)
 #endif
 
 // K4: calculate_qoe in the reference's operation order (Simulator.py:79-86)
@@ -986,17 +1005,30 @@ extern "C" int abr_env_destroy(abr_env *env) {
     return ABR_OK;
 }
 
+// which implementations this build of the library can run (abr_env_set_impl): the product holds 0, 1, 2, 3, 5
+extern "C" int abr_env_has_impl(int32_t impl) {
+    switch (impl) {
+    case 0: case 1: case 2: case 3: case 5: return 1;
+#ifdef ABR_WITH_ASYNC
+    case 4: return 1;
+#endif
+#ifdef ABR_WITH_RING
+    case 6: return 1;
+#endif
+    default: return 0;
+    }
+}
+
 // 3 = auto (default), 5 / 2 = role-split event-driven kernels (three / two waves per 64 lanes),
 // 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
     if (impl < 0 || impl > 6)
-        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto), 5 (split3) or 6 (ring3)");
-#ifndef ABR_WITH_ASYNC
-    if (impl == 4)
-        return fail(ABR_E_UNSUPPORTED, "impl 4 (the asynchronous pipeline) is not part of the product library: "
-                    "it is slower than what `auto` selects; the diagnostic build libabr_hip_async.so carries it");
-#endif
+        return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 5 (split3)");
+    if (!abr_env_has_impl(impl))
+        return fail(ABR_E_UNSUPPORTED, "impl %d (4: the asynchronous pipeline, 6: the ring-coupled role pipeline) is not part of "
+                    "the product library: it is slower than what `auto` selects; the diagnostic build "
+                    "tools/diag/lib/libabr_hip_diag.so carries it", impl);
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))
         return fail(ABR_E_UNSUPPORTED, "the tick-by-tick kernels take one speed for all lanes");
     env->impl = impl;
@@ -1094,10 +1126,14 @@ static inline bool is_split(int impl) { return impl == 2 || impl == 5 || impl ==
 template <int MODE>
 static void launch_split(int impl, const EnvParams &p, const int32_t *actions, float *obs, float *rew, uint8_t *dn,
                          int32_t *acts, int32_t n_steps, uint64_t seed, hipStream_t st) {
-    if (impl == 6)
+#ifdef ABR_WITH_RING
+    if (impl == 6) {
         hipLaunchKernelGGL(env_ring3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(64 * ABR_RING_WAVES), 0, st, p, actions, obs, rew,
                            dn, acts, n_steps, seed);
-    else if (impl == 5)
+        return;
+    }
+#endif
+    if (impl == 5)
         hipLaunchKernelGGL(env_split3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(192), 0, st, p, actions, obs, rew,
                            dn, acts, n_steps, seed);
     else

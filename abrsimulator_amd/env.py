@@ -52,12 +52,10 @@ class BatchedABREnv:
     def __init__(self, mpd: MPD, qoe_metric: QOEMetric, network_info: NetworkInfo, n_lanes: int,
                  device="cuda", speed=1.0, auto_reset: bool = False, max_ticks: int = 0,
                  lane_id_base: int = 0, impl: str = "auto", library: Optional[str] = None):
-        # `library`: a diagnostic build of the same ABI in csrc/ (csrc/Makefile).  The product library holds
-        # only what `auto` can select plus the jump / split / tick cross-checks; impl="async" (the asynchronous
-        # pipeline: measured slower, kept for the parity tests and records) lives in _lib.ASYNC_SO and is
-        # loaded from there -- an ImportError if that diagnostic library has not been built.
-        if impl == "async" and library is None and not os.environ.get("ABR_HIP_LIB"):
-            library = _lib.ASYNC_SO
+        # `library`: a diagnostic build of the same ABI (tools/diag/csrc/Makefile -> tools/diag/lib), by path or file
+        # name.  The product library holds only what `auto` can select plus the jump / split / tick cross-checks;
+        # impl="async" / "ring3" (pipelines that were measured slower, kept for the parity tests and the records)
+        # need such a library and are refused (ABR_E_UNSUPPORTED) by the product.
         self.lib = _lib.lib(library)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -134,8 +132,8 @@ class BatchedABREnv:
         if impl not in impls:
             raise ValueError("impl must be 'auto' (default: the fastest at this size, see effective_impl()), "
                              "'split' / 'split3' (role-split event-driven kernels, two / three waves per 64 lanes), "
-                             "'jump' (event-driven, one thread per lane) or 'tick' ('async' only with "
-                             "library=_lib.ASYNC_SO, the diagnostic build that carries the asynchronous pipeline)")
+                             "'jump' (event-driven, one thread per lane) or 'tick' ('async' / 'ring3' only with "
+                             "library=<a diagnostic build that carries them>)")
         self.impl = impl
         self._check(self.lib.abr_env_set_impl(self._h, impls[impl]))
         if self.lane_speeds is not None:
@@ -186,19 +184,25 @@ class BatchedABREnv:
         return t
 
     # -- the step surface --------------------------------------------------
-    def reset(self, trace_id=None, start_offset=None, mask=None):
-        """Simulator.py:95-133 + idle ticks to the first ABR call.  Default
-        assignment: lane i -> trace i % n_traces, offset 0."""
+    def reset(self, trace_id=None, start_offset=None, mask=None, check=False):
+        """Simulator.py:95-133 + idle ticks to the first ABR call.  Default assignment: lane i -> trace
+        i % n_traces, offset 0.  `mask`: only lanes with a non-zero byte are reset (a masked reset inside an RL loop).
+
+        No device-to-host synchronisation happens here: a lane whose trace id is outside [0, n_traces) or whose start
+        offset is negative is frozen ON THE DEVICE with ABR_DONE_BADARG in its done byte (the reference would raise
+        IndexError at Simulator.py:159).  check=True validates on the host first and raises ValueError instead -- at the
+        price of two synchronisations."""
         if trace_id is None:
             trace_id = torch.arange(self.n_lanes, device=self.device, dtype=torch.int32) % self.n_traces
         self.trace_id = self._i32(trace_id, "trace_id")
-        if int(self.trace_id.min()) < 0 or int(self.trace_id.max()) >= self.n_traces:
-            raise ValueError("trace_id out of range")
         if start_offset is None:
             start_offset = torch.zeros(self.n_lanes, dtype=torch.int32, device=self.device)
         self.start_offset = self._i32(start_offset, "start_offset")
-        if int(self.start_offset.min()) < 0:
-            raise ValueError("start_offset must be >= 0")
+        if check:
+            if int(self.trace_id.min()) < 0 or int(self.trace_id.max()) >= self.n_traces:
+                raise ValueError("trace_id out of range")
+            if int(self.start_offset.min()) < 0:
+                raise ValueError("start_offset must be >= 0")
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
@@ -264,8 +268,9 @@ class BatchedABREnv:
         return out
 
     def effective_impl(self, fused: bool = False):
-        """Name of the kernels the handle resolves to right now ('auto' is a policy, not a kernel):
-        fused=True for step_random / step_script, False for step."""
+        """Name of the kernels the handle resolves to right now ('auto' is a policy, not a kernel): fused=True for a
+        step_random / step_script call of MORE than one decision, False for launches of one decision (step, step_mpc,
+        and a fused call with n_steps == 1) -- under 'auto' those resolve to 'jump' at every size (include/abr_env.h)."""
         v = C.c_int32()
         self._check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
         return {0: "jump", 1: "tick", 2: "split", 4: "async", 5: "split3", 6: "ring3"}[v.value]

@@ -114,9 +114,169 @@ class ObsRewardGather:
         return (g[:, :self.n_obs].reshape((self.world,) + self.obs_shape),
                 g[:, self.n_obs:].reshape((self.world,) + self.reward_shape))
 
+    def wait_done(self, b):
+        """The caller's stream waits until the gather into buffer b has finished (its result may then be read)."""
+        if self.cuda and self.pending[b] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.pending[b])
+
     def finish(self):
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
+class ShardStep:
+    """What one launch of a ShardedABREnv returns: `local` -- this rank's outputs (dict obs [F, OBS_DIM, n], reward [F, n],
+    done [F, n], actions [F, n] or None; views of the launch's slab, valid until the launch after next reuses it) -- and the
+    handle to the ONE collective of the launch: gathered() -> (obs [world, OBS_DIM, n_max], reward [world, F, n_max]) of
+    every rank's final observation and rewards once the all-gather has finished; unsharded() the same in global lane order."""
+
+    def __init__(self, owner, buf, local, views):
+        self._owner, self._buf, self.local, self._views = owner, buf, local, views
+
+    def gathered(self):
+        if self._views is None:
+            raise RuntimeError("this launch was not gathered (gather=False, or a launch shape other than `fuse`)")
+        self._owner._gather.wait_done(self._buf)
+        return self._views
+
+    def unsharded(self):
+        go, gr = self.gathered()
+        return unshard_lanes(go, self._owner.counts), unshard_lanes(gr, self._owner.counts)
+
+
+class ShardedABREnv:
+    """One rank's shard of ONE batched environment of `total_lanes` lanes spread over the ranks of a process group
+    (one process per GPU).  Owns everything the N > 1 composition consists of: the shard's lane range
+    (shard_range), the global lane ids of the counter-based policy (lane_id_base), the global lane -> (trace, offset)
+    map (lane_assignment), two slabs the kernel writes (obs, reward) into, and THE one collective of the path -- a
+    single all_gather_into_tensor of the packed [final observation | rewards] per launch (ObsRewardGather: RCCL over
+    xGMI on the GPU box, gloo in the CPU tests), issued on a side stream and double-buffered so that it overlaps the next
+    launch.  An N-rank run reproduces the 1-rank run lane for lane.
+
+        env = ShardedABREnv(mpd, qoe, net, total_lanes=1048576, fuse=48)       # rank / world from torch.distributed
+        env.reset()
+        st = env.step_random(48, seed)        # this rank's launch; the all-gather is in flight
+        st2 = env.step_random(48, seed)       # overlaps it
+        obs, reward = st.gathered()           # [world, 8, n_max], [world, 48, n_max]
+        env.finish()
+
+    lanes_per_rank: weak scaling instead -- every rank gets that many lanes (total = world * lanes_per_rank).
+    `env`: the per-rank stepper (default: a BatchedABREnv on `device`); anything with n_lanes, reset(trace_id, offset),
+    step_random / step_script(out=) works -- the gloo tests put a CPU stand-in there."""
+
+    def __init__(self, mpd, qoe_metric, network_info, total_lanes=None, lanes_per_rank=None, fuse=48, device="cuda",
+                 group=None, rank=None, world=None, gather=True, obs_dim=8, env=None, **env_kw):
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        self.rank, self.world, self.group = int(rank), int(world), group
+        if (total_lanes is None) == (lanes_per_rank is None):
+            raise ValueError("give total_lanes (strong scaling) or lanes_per_rank (weak scaling)")
+        if lanes_per_rank is not None:
+            total_lanes = int(lanes_per_rank) * self.world
+        self.total_lanes = int(total_lanes)
+        self.lane0, self.n_lanes = shard_range(self.total_lanes, self.world, self.rank)
+        self.counts = [shard_range(self.total_lanes, self.world, r)[1] for r in range(self.world)]
+        self.n_max = max(self.counts)
+        self.fuse, self.obs_dim = int(fuse), int(obs_dim)
+        self.device = torch.device(device)
+        self.network_info = network_info
+        if env is None:
+            from .env import BatchedABREnv
+            env = BatchedABREnv(mpd, qoe_metric, network_info, self.n_lanes, device=self.device,
+                                lane_id_base=self.lane0, **env_kw)
+        self.env = env
+        # the collective runs whenever a process group exists (a ONE-rank group too: the same code path as N ranks)
+        self._do_gather = bool(gather) and dist.is_available() and dist.is_initialized()
+        F, D, n = self.fuse, self.obs_dim, self.n_lanes
+        self._slabs = [make_slab(F, D, n, self.device) for _ in range(2)]
+        self._done = [torch.empty(F, n, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self._acts = [None, None]
+        self._outs = [self._bind(dict(obs=o, reward=r, done=self._done[b], actions=None))
+                      for b, (_, o, r, _) in enumerate(self._slabs)]
+        self._gather = ObsRewardGather((D, self.n_max), (F, self.n_max), self.device, group=group) if self._do_gather else None
+        # uneven shards: the collective needs equal parts, so a smaller shard sends through a zero-padded staging copy
+        self._stage = ([torch.zeros(D + F, self.n_max, dtype=torch.float32, device=self.device) for _ in range(2)]
+                       if self._do_gather and n != self.n_max else None)
+        self._it = 0
+
+    def _bind(self, out):
+        return self.env.bind_out(out) if hasattr(self.env, "bind_out") else out
+
+    # ---- the global lane -> (trace, offset) map ----
+    def lane_map(self, xcd_groups=0):
+        bw = self.network_info.bandwidths
+        lens = [len(t) for t in (bw if hasattr(bw[0], "__len__") else [bw])]
+        return lane_assignment(self.lane0, self.n_lanes, lens, xcd_groups=xcd_groups)
+
+    def reset(self, trace_id=None, start_offset=None, mask=None):
+        """Default: the deterministic global-lane map (lane_assignment); or this shard's own trace ids / offsets."""
+        if trace_id is None:
+            trace_id, start_offset = self.lane_map()
+        tid = torch.as_tensor(trace_id)
+        off = None if start_offset is None else torch.as_tensor(start_offset)
+        return self.env.reset(tid, off) if mask is None else self.env.reset(tid, off, mask)
+
+    # ---- launches ----
+    def _launch(self, n_steps, call, events=None):
+        """`call(out)` runs the launch into the dict `out`; returns the ShardStep with the collective in flight.
+        events: an optional (start, end) pair of HIP events recorded right around the kernel launch itself."""
+        if n_steps != self.fuse:                       # an odd launch shape: local outputs only
+            if events:
+                events[0].record()
+            local = call(None)
+            if events:
+                events[1].record()
+            return ShardStep(self, None, local, None)
+        b = self._it & 1
+        self._it += 1
+        if self._gather is not None:
+            self._gather.wait_free(b)                  # slab b's previous gather has read it
+        if events:
+            events[0].record()
+        local = call(self._outs[b])
+        if events:
+            events[1].record()
+        views = None
+        if self._gather is not None:
+            send = self._slabs[b][3]
+            if self._stage is not None:
+                st = self._stage[b]
+                st[:, :self.n_lanes].copy_(send.view(self.obs_dim + self.fuse, self.n_lanes))
+                send = st.view(-1)
+            views = self._gather.gather(b, send)
+        return ShardStep(self, b, local, views)
+
+    def step_random(self, n_steps, seed, events=None):
+        """n_steps fused decisions per lane under the built-in counter-based policy (global lane ids)."""
+        return self._launch(int(n_steps), lambda out: self.env.step_random(int(n_steps), seed, out=out), events)
+
+    def step_script(self, actions):
+        """actions int32 [n_steps, n_lanes] of THIS shard's lanes."""
+        n = int(actions.shape[0])
+        return self._launch(n, lambda out: self.env.step_script(actions, out=out))
+
+    def step_mpc(self, controller, n_steps):
+        """n_steps decisions taken by `controller` on this shard's own state (actions are computed where the lane lives;
+        only (obs, reward) is gathered)."""
+        n = int(n_steps)
+
+        def call(out):
+            if out is not None and out.get("actions") is None:
+                out = dict(out)
+                out["actions"] = torch.empty(n, self.n_lanes, dtype=torch.int32, device=self.device)
+            return self.env.step_mpc(controller, n, out=out)
+        return self._launch(n, call)
+
+    @property
+    def n_collectives(self):
+        return self._gather.n_collectives if self._gather is not None else 0
+
+    def finish(self):
+        """The caller's stream waits for every collective in flight."""
+        if self._gather is not None:
+            self._gather.finish()
 
 
 def unshard_lanes(gathered, counts):

@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
-V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, 20.0, 8.0, 1.0
+V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, float(os.environ.get("ABR_BENCH_MAX_BUFFER", "20.0")), 8.0, 1.0   # (the override is a diagnostic: 1e9 = buffer_full never gates a download)
 WEIGHTS = [4.3, 1.0, 1.0, 0.1]
 N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000   # (the override is a cache-residency diagnostic)
 STRONG_TOTAL = int(os.environ.get("ABR_BENCH_STRONG_TOTAL", "1048576"))   # configs[3] / north_star: the scaling
@@ -264,6 +264,7 @@ def main():
                          "is reported, so that one sub-millisecond launch is not the whole sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="env_random, N=1: skip the sustained block")
+    ap.add_argument("--no-single-step", action="store_true", help="env_random, N=1: skip the single_step block (abr_env_step launches)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0)
     ap.add_argument("--no-mpc-rollout", action="store_true",
                     help="env_random, N=1: skip the mpc_rollout block (BASELINE.json configs[2] composed and configs[4]'s per-rank shape)")
@@ -320,7 +321,7 @@ def main():
 
     import abrsimulator_amd as A
     from abrsimulator_amd._lib import OBS_DIM
-    from abrsimulator_amd.sharding import ObsRewardGather, make_slab, shard_range
+    from abrsimulator_amd.sharding import ShardedABREnv, shard_range
 
     if a.total_lanes:
         lane0, N = shard_range(a.total_lanes, world, rank)       # strong scaling
@@ -376,37 +377,36 @@ def main():
                     events.append((e0, e1, 1))
         return run
 
-    def make_random_runner(env_, N_, F_, events_, use_graph, gather_on=True):
-        """The env_random step loop over `env_`: launches of F_ fused decisions into double-buffered
-        slabs; with more than one rank THE one collective of the path per launch -- ONE all-gather of
-        the packed slab [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with
-        the next launch.  The intermediate observations of a fused launch are consumed on-device by the
-        built-in policy and stay in the local slab; at --fuse 1 every observation is gathered
-        (configs[3] literally)."""
-        slabs = [make_slab(F_, OBS_DIM, N_, dev) for _ in range(2)]
-        bufs = [env_.bind_out(dict(obs=o, reward=r, done=torch.empty(F_, N_, dtype=torch.uint8, device=dev),
-                                   actions=None)) for (_, o, r, _) in slabs]
+    def make_random_runner(env_, N_, F_, events_, use_graph, gather_on=True, total_=None, lane0_=None):
+        """The env_random step loop over `env_`, through the package's ShardedABREnv (abrsimulator_amd/sharding.py): launches
+        of F_ fused decisions into double-buffered slabs; with more than one rank THE one collective of the path per launch
+        -- ONE all-gather of the packed slab [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with
+        the next launch.  The intermediate observations of a fused launch are consumed on-device by the built-in policy and
+        stay in the local slab; at --fuse 1 every observation is gathered (configs[3] literally)."""
         gather = (world > 1 or force_dist) and not a.no_gather and gather_on
-        gat_ = ObsRewardGather((OBS_DIM, N_), (F_, N_), dev) if gather else None
+        sh = ShardedABREnv(None, None, env_.network_info, lanes_per_rank=N_, fuse=F_, device=dev, gather=gather, env=env_,
+                           rank=rank, world=world)
+        assert sh.n_lanes == N_
+        gat_ = sh._gather
         graph = None
         if use_graph:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                env_.step_random(F_, a.seed, out=bufs[0])   # warm-up on a side stream before capture
+                env_.step_random(F_, a.seed, out=sh._outs[0])   # warm-up on a side stream before capture
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                env_.step_random(F_, a.seed, out=bufs[0])
+                env_.step_random(F_, a.seed, out=sh._outs[0])
 
         pool = []      # HIP events are created on their first record(): do that outside the timed region
-        info = dict(n_done=0, last=None, bufs=bufs, slabs=slabs)     # decisions run so far; (buffer, decisions, first decision) of the last launch
+        info = dict(n_done=0, last=None, bufs=sh._outs, sharded=sh)     # decisions run so far; (buffer, decisions, first decision) of the last launch
 
         def take():
             return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
 
         def run_(n_steps, timed):
-            left, it = n_steps, 0
+            left = n_steps
             if not timed:                                 # warm-up call: stock the pool for the timed calls
                 need = 2 * (max(1, -(-a.min_timed_steps // max(K, 1))) + 1) * (K // F_ + 2)
                 while len(pool) < need:
@@ -422,23 +422,15 @@ def main():
                 left -= F_
             while left > 0:
                 f = min(F_, left)
-                b = it & 1
-                if gather:
-                    gat_.wait_free(b)                     # slab b has been gathered: reusable
+                evp = (take(), take()) if timed else None
+                b = sh._it & 1
+                sh.step_random(f, a.seed, events=evp)     # wait for the slab, launch, enqueue the all-gather
                 if timed:
-                    e0 = take(); e0.record()
-                env_.step_random(f, a.seed, out=bufs[b] if f == F_ else None)
-                if timed:
-                    e1 = take(); e1.record()
-                    events_.append((e0, e1, f))
-                if gather and f == F_:
-                    gat_.gather(b, slabs[b][3])
+                    events_.append((evp[0], evp[1], f))
                 info["last"] = (b, f, info["n_done"]) if f == F_ else None
                 info["n_done"] += f
                 left -= f
-                it += 1
-            if gather:
-                gat_.finish()
+            sh.finish()
         run_.info = info
         return run_, gat_
 
@@ -535,6 +527,23 @@ def main():
                      "windows_100ms": len(win), "min_window_value": min(win) if win else None,
                      "note": "one bracket (barrier + synchronize on both sides) around all launches; the windows are HIP "
                              "events recorded every ~100 ms inside it"}
+
+    # ---- the reset()/get_video_chunk(quality) surface itself (N = 1): ONE decision per launch with the caller's actions,
+    #      abr_env_step (Simulator.py:155's call site turned inside out) ----
+    single_step = None
+    if a.workload == "env_random" and world == 1 and not a.no_single_step:
+        acts1 = torch.randint(0, len(LADDER), (N,), dtype=torch.int32, device=dev)
+        for _ in range(50):
+            env.step(acts1)
+        n1 = 400
+        barrier(); t0 = time.perf_counter()
+        for _ in range(n1):
+            env.step(acts1)
+        barrier()
+        el1 = time.perf_counter() - t0
+        single_step = {"metric": "env_steps_per_sec_single_decision_launches", "value": N * n1 / el1, "unit": "env-steps/s",
+                       "launches": n1, "us_per_launch": el1 / n1 * 1e6, "impl": env.effective_impl(fused=False),
+                       "call": "abr_env_step(actions): one decision per launch, caller-supplied actions (a fixed random vector)"}
 
     def env_roofline():
         # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
@@ -705,8 +714,8 @@ def main():
                 e2.record()
                 evs.append((e0, e1, e2))
             torch.cuda.synchronize(dev)
-            k3 = float(np.mean([x.elapsed_time(y) for x, y, _ in evs])) * 1e3
-            k1 = float(np.mean([y.elapsed_time(z) for _, y, z in evs])) * 1e3
+            k3 = float(np.median([x.elapsed_time(y) for x, y, _ in evs])) * 1e3
+            k1 = float(np.median([y.elapsed_time(z) for _, y, z in evs])) * 1e3
             mpc_rollout[name] = {
                 "metric": "env_steps_per_sec_mpc_policy", "value": lanes_r * V / el_r, "unit": "env-steps/s",
                 "combos_per_sec": lanes_r * V * 6 ** 5 / el_r, "lanes": lanes_r, "lane_id_base": base_r,
@@ -714,7 +723,8 @@ def main():
                 "traces": f"{N_TRACES} x " + ("300..3000" if mixed_r else str(TRACE_LEN)),
                 "episodes_ended_at_last_decision": ends, "call": "abr_env_step_mpc(n_steps=48): K3 + K1 per decision, no host work between",
                 "split_host_loop": {"k3_select_us": k3, "k1_step_us": k1, "k1_impl": env_r.effective_impl(fused=False),
-                                    "note": "HIP events around next_bitrate() and step() of a host loop over one more episode"}}
+                                    "note": "medians of HIP events around next_bitrate() and step() (+ one clamp kernel) of a host "
+                                            "loop over one more episode"}}
             del env_r, ctl_r, out_r
             torch.cuda.empty_cache()
 
@@ -754,6 +764,8 @@ def main():
             line["selfcheck"] = selfcheck
         if sustained is not None:
             line["sustained"] = sustained
+        if single_step is not None:
+            line["single_step"] = single_step
         if mpc_rollout is not None:
             line["mpc_rollout"] = mpc_rollout
         if control is not None:

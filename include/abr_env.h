@@ -37,14 +37,16 @@
 extern "C" {
 #endif
 
-/* 2: abr_env_step_script, abr_env_get_effective_impl, abr_env_notify_restore, impl 5 (three waves per 64
+/* 3: abr_env_has_impl (which implementations THIS build of the library carries: the product answers 0 for the rejected
+ * pipelines 4 and 6, which abr_env_set_impl refuses with ABR_E_UNSUPPORTED); under impl 3 (auto) a launch of ONE decision
+ * resolves to 0 at every size (abr_env_get_effective_impl(fused = 0)); ABR_DONE_INTERNAL is reserved for the diagnostic
+ * pipelines' watchdogs.  A version-2 host keeps working: nothing it could call changed its signature.
+ * 2: abr_env_step_script, abr_env_get_effective_impl, abr_env_notify_restore, impl 5 (three waves per 64
  * lanes); struct abr_mpc_options GREW (mask_is_done + reserved_ appended: a version-1 host passes a
  * shorter struct and must be rebuilt); since 1 also: workspace layout grew, abr_env_set_lane_speeds /
  * _speed_schedule / _bitrate_table are latched until the next full reset, every re-reset advances the
- * policy's episode counter, default impl is 3 (auto).  A host built against version 1 must be rebuilt.
- * (impl 4, the asynchronous pipeline of round 3, is no longer part of the product library: it lost to
- * what `auto` selects; csrc/Makefile: libabr_hip_async.so is a diagnostic build that still carries it.) */
-#define ABR_ABI_VERSION 2
+ * policy's episode counter, default impl is 3 (auto).  A host built against version 1 must be rebuilt. */
+#define ABR_ABI_VERSION 3
 #define ABR_MAX_RATES 16
 #define ABR_MAX_HORIZON 8
 
@@ -176,10 +178,17 @@ int abr_env_notify_restore(abr_env *env);
  * time, history, reward, observation, episode end);
  * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 98 304 lanes,
  * 0 above -- and 0 at every size for launches of ONE decision (abr_env_step, the per-decision
- * launches of abr_env_step_mpc, a fused call with n_steps == 1).  All produce identical state and outputs (the workspace is interchangeable between
- * them); 1 exists as an independent cross-check.  4 (the asynchronous pipeline) is answered with
- * ABR_E_UNSUPPORTED by the product library. */
+ * launches of abr_env_step_mpc, a fused call with n_steps == 1).
+ * 0, 2 and 5 produce identical state and outputs in every case (the workspace is interchangeable between them, also
+ * mid-episode).  1 is an independent cross-check: it agrees with them on every lane that ends its episode, but it visits
+ * ticks in blocks, so a lane that runs into max_ticks (ABR_DONE_TIMEOUT -- build-defined: the reference has no time-out)
+ * is frozen at its block boundary: same done bits, different frozen counters in that lane's last observation.
+ * 4 (the asynchronous pipeline of round 3) and 6 (the ring-coupled role pipeline of round 5) were measured slower than what
+ * 3 selects and are not in the product library: ABR_E_UNSUPPORTED, see abr_env_has_impl. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
+
+/* 1 if this build of the library can run implementation `impl` (0..6), else 0.  The product library: 0, 1, 2, 3, 5. */
+int abr_env_has_impl(int32_t impl);
 
 /* The implementation (0, 1, 2 or 5; never 3) the handle resolves to right now: fused != 0 for
  * abr_env_step_random / abr_env_step_script with more than one decision per call, 0 for launches of
@@ -216,8 +225,9 @@ int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs_out_dev,
  * n_steps fused decisions per lane with the built-in random policy
  * action = philox4x32-10(key=seed, ctr=(lane, episode_step, episode_no, 0)) % n_rates.
  * Outputs (all nullable) are [n_steps][...] slabs: obs [n_steps][ABR_OBS_DIM][n_lanes],
- * reward/done/actions [n_steps][n_lanes].  Lanes progress independently (no
- * per-step rendezvous), which is what removes the divergent-while-loop tail.
+ * reward/done/actions [n_steps][n_lanes].  Lane state is read and written once per call.  Under the one-thread-per-lane
+ * kernels (impl 0) lanes progress independently; the role-split kernels (impl 2 / 5) meet at ONE workgroup barrier per
+ * decision (64 lanes, two or three waves), which is what `auto` prefers up to 98 304 lanes.
  */
 int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed, float *obs_out_dev,
                         float *reward_out_dev, uint8_t *done_out_dev, int32_t *actions_out_dev,

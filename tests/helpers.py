@@ -1,12 +1,35 @@
 """Shared helpers for the parity tests (tests may use the oracle; the product may not)."""
+import os
+import subprocess
+
 import numpy as np
 
 
 from oracle.oracle import philox_action  # noqa: E402,F401  (bit-exact numpy twin of the device policy)
 
 
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG_IMPLS = ("async", "ring3")      # pipelines that were measured slower and live in the diagnostic build only
+
+
+def diag_lib():
+    """tools/diag/lib/libabr_hip_diag.so -- the product's translation unit plus the rejected pipelines (impl 'async',
+    'ring3') -- built on demand (hipcc, ~40 s) when missing or older than its sources.  Tests name it explicitly
+    (BatchedABREnv(library=...)); the product package never loads it by itself."""
+    d = os.path.join(_ROOT, "tools", "diag", "csrc")
+    so = os.path.join(_ROOT, "tools", "diag", "lib", "libabr_hip_diag.so")
+    srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
+    c = os.path.join(_ROOT, "abrsimulator_amd", "csrc")
+    srcs += [os.path.join(c, f) for f in os.listdir(c) if f.endswith((".h", ".hip"))]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", d, "-s", "../lib/libabr_hip_diag.so"], stderr=subprocess.DEVNULL)
+    return so
+
+
 def make_env(meta, traces, n_lanes, device="cuda", **kw):
     import abrsimulator_amd as A
+    if kw.get("impl") in DIAG_IMPLS and "library" not in kw:
+        kw["library"] = diag_lib()
     mpd = A.MPD(meta["video_length"], meta["chunk_length"], meta["max_buffer"],
                 meta["start_up_length"], A.Chunk(meta["ladder"]))
     qoe = A.QOEMetric(*meta["weights"])

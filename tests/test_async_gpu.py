@@ -306,9 +306,17 @@ def test_auto_resolves_to_the_measured_fastest():
     env = make_env(BENCH_META, traces, 98305)
     assert env.effective_impl(fused=True) == "jump" and env.effective_impl(fused=False) == "jump"
     import abrsimulator_amd as A
-    with pytest.raises(A._lib.AbrError):          # impl 4 is refused by the product library
-        _lib = A._lib.lib()
-        A._lib.check(_lib.abr_env_set_impl(env._h, 4), _lib)
+    _lib = A._lib.lib()
+    for impl_no in (4, 6):                        # the rejected pipelines are refused by the product library ...
+        assert _lib.abr_env_has_impl(impl_no) == 0
+        with pytest.raises(A._lib.AbrError):
+            A._lib.check(_lib.abr_env_set_impl(env._h, impl_no), _lib)
+    assert all(_lib.abr_env_has_impl(i) == 1 for i in (0, 1, 2, 3, 5))
+    from helpers import diag_lib
+    diag = A._lib.lib(diag_lib())                 # ... and carried by the diagnostic build, which tests name explicitly
+    assert diag.abr_env_has_impl(4) == 1 and diag.abr_env_has_impl(6) == 1
+    with pytest.raises(A._lib.AbrError):          # the package never loads that build by itself
+        make_env(BENCH_META, traces, 512, impl="ring3", library=A._lib.SO_PATH)
 
 
 def test_per_chunk_ladders_on_the_async_pipeline(oracle):
@@ -322,8 +330,9 @@ def test_per_chunk_ladders_on_the_async_pipeline(oracle):
     outs = {}
     for impl in FUSED_IMPLS:
         mpd = A.MPD(V, 4.0, 20.0, 8.0, [A.Chunk(list(r)) for r in table])
+        from helpers import DIAG_IMPLS, diag_lib
         env = A.BatchedABREnv(mpd, A.QOEMetric(4.3, 1, 1, 0.1), A.NetworkInfo(1.0, traces), N, auto_reset=True,
-                              impl=impl)
+                              impl=impl, library=diag_lib() if impl in DIAG_IMPLS else None)
         env.reset()
         outs[impl] = (env.step_random(3 * V, 17), env.episode_qoe().clone())
     for impl in FUSED_IMPLS[1:]:

@@ -318,7 +318,11 @@ def test_reset_with_bad_trace_id_or_offset_freezes_the_lane():
         assert (d[[3, 9, 17]] == _lib.DONE_BADARG).all() and (np.delete(d, [3, 9, 17]) == 0).all()
         assert torch.equal(obs0[impl], obs0["split"]), impl
     with pytest.raises(ValueError):
-        env.reset(tid.cpu(), off.cpu())                      # the Python front end refuses outright
+        env.reset(tid.cpu(), off.cpu(), check=True)          # the Python front end refuses outright when asked to look
+    # ... and by default takes the device's word: no host synchronisation in reset(), the lanes are frozen with BADARG
+    env.reset(tid.cpu(), off.cpu())
+    _, _, done = env.step(torch.zeros(128, dtype=torch.int32).cuda())
+    assert (done.cpu().numpy()[[3, 9, 17]] == _lib.DONE_BADARG).all()
 
 
 def test_lane_speeds_are_latched_until_a_full_reset(oracle):
@@ -407,7 +411,9 @@ def test_per_chunk_ladders_against_oracle(oracle, impl, tmp_path):
     assert not mpd.uniform() and np.array_equal(np.array(mpd.bitrate_table()), br)
     tid = rng.integers(0, 8, N).astype(np.int32); off = rng.integers(0, 1000, N).astype(np.int32)
     actions = rng.integers(0, 6, (N, VV)).astype(np.int32)
-    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(1.0, traces), N, impl=impl)
+    from helpers import DIAG_IMPLS, diag_lib
+    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(1.0, traces), N, impl=impl,
+                          library=diag_lib() if impl in DIAG_IMPLS else None)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
     cfg = oracle.env_cfg(LADDER, L, VV, MAX_BUFFER, START_UP, 1.0, WEIGHTS, 1.0, br_table=br)
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, tid, off, actions)

@@ -619,8 +619,9 @@ def test_resume_into_a_freshly_built_env(oracle, impl):
 
     def build():
         mpd = A.MPD(V, 2.0, 12.0, 4.0, [A.Chunk(list(r)) for r in table])
+        from helpers import DIAG_IMPLS, diag_lib
         return A.BatchedABREnv(mpd, A.QOEMetric(4.3, 1, 1, 0.1), A.NetworkInfo(1.0, traces), N, speed=sched,
-                               impl=impl)
+                               impl=impl, library=diag_lib() if impl in DIAG_IMPLS else None)
 
     ref = build(); ref.reset(tid, off)
     ref_out = ref.step_script(acts)

@@ -1,8 +1,9 @@
-"""world_size-2 and world_size-8 gloo tests of the N>1 path on CPU: shard ranges, the global-lane
-trace map, the counter-based policy under lane_id_base, and the one collective
-(all-gather of (obs, reward)).  The per-rank stepper here is the ORACLE (tests
-may use it; the product path is the HIP kernels, exercised by the -m gpu tests
-with the same lane_id_base contract in test_env_gpu.py::test_auto_reset_and_lane_id_base)."""
+"""world_size-2 and world_size-8 gloo tests of the N>1 path on CPU, through the package's ShardedABREnv
+(abrsimulator_amd/sharding.py): shard ranges, the global-lane trace map, the counter-based policy under
+lane_id_base, slabs, the staging copy of uneven shards, double buffering, and the one collective (all-gather of
+(obs, reward)).  The per-rank stepper plugged into the class here is the ORACLE (tests may use it; the product's
+stepper is the HIP library, exercised by the -m gpu tests with the same lane_id_base contract in
+test_env_gpu.py::test_auto_reset_and_lane_id_base and by the two-rank HIP-shard test)."""
 import os
 import socket
 
@@ -27,19 +28,55 @@ LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
 V, SEED, TOTAL = 6, 1234, 101
 
 
-def _rollout(lane0, n, traces):
-    """obs [V, 3, n] / reward [V, n] of lanes lane0..lane0+n with the philox policy."""
+WEIGHTS = [4.3, 1, 1, 0.1]
+
+
+def _rollout(lane0, n, traces, tid=None, off=None):
+    """obs [V, 8, n] / reward [V, n] float32 of lanes lane0..lane0+n with the philox policy, as a fused launch of V
+    decisions writes them: the observation after decision s is the run() frame at call site s + 1 (the last one: the
+    frame calculate_qoe was called from); rewards from the oracle's timers (oracle.step_rewards)."""
     import sys
     sys.path.insert(0, ROOT)
     from abrsimulator_amd.sharding import lane_assignment
     from oracle import oracle as O
-    tid, off = lane_assignment(lane0, n, [len(t) for t in traces])
-    acts = np.stack([O.philox_action(SEED, np.arange(lane0, lane0 + n), s, 0, 6) for s in range(V)], 1)
-    cfg = O.env_cfg(LADDER, 4.0, V, 20.0, 8.0, 1.0, [4.3, 1, 1, 0.1], 1.0)
-    steps, bw, fin, _ = O.env_batch(cfg, traces, tid, off, acts.astype(np.int32))
-    obs = np.stack([steps["buffer_level"].T, steps["global_time"].T, steps["last_bandwidth"].T], 1)
-    rew = 4.3 * np.diff(np.concatenate([steps["rebuffer_time"], fin["rebuffer_time"][:, None]], 1), axis=1).T
-    return obs.astype(np.float32), rew.astype(np.float32)
+    if tid is None:
+        tid, off = lane_assignment(lane0, n, [len(t) for t in traces])
+    acts = np.stack([O.philox_action(SEED, np.arange(lane0, lane0 + n), s, 0, 6) for s in range(V)], 1).astype(np.int32)
+    cfg = O.env_cfg(LADDER, 4.0, V, 20.0, 8.0, 1.0, WEIGHTS, 1.0)
+    steps, bw, fin, _ = O.env_batch(cfg, traces, np.asarray(tid), np.asarray(off), acts)
+    obs = np.zeros((V, 8, n), np.float32)
+    for s in range(V - 1):
+        q = s + 1
+        rows = [steps["chunk_id"][:, q], acts[:, s], steps["last_bandwidth"][:, q], steps["buffer_level"][:, q],
+                steps["global_time"][:, q], steps["play_time"][:, q], steps["rebuffer_time"][:, q], steps["start_up_time"][:, q]]
+        obs[s] = np.stack([np.asarray(r, np.float64).astype(np.float32) for r in rows])
+    rows = [fin["chunk_id"], acts[:, V - 1], bw[:, V - 1], fin["buffer_level"], fin["global_time"], fin["play_time"],
+            fin["rebuffer_time"], fin["start_up_time"]]
+    obs[V - 1] = np.stack([np.asarray(r, np.float64).astype(np.float32) for r in rows])
+    rew = O.step_rewards(steps["rebuffer_time"], steps["start_up_time"], fin["rebuffer_time"], fin["start_up_time"],
+                         acts, WEIGHTS, ladder=LADDER)
+    return obs, rew.T.copy()
+
+
+class OracleShardEnv:
+    """CPU stand-in for BatchedABREnv inside ShardedABREnv: the same n_lanes / reset / step_random(out=) surface, stepped
+    by the oracle (tests may use it; the product's stepper is the HIP library).  Everything else the gloo tests exercise --
+    shard ranges, global lane ids, the lane map, slabs, the staging copy of uneven shards, the one collective, the
+    double buffering -- is the package's ShardedABREnv itself."""
+
+    def __init__(self, traces, lane0, n):
+        self.traces, self.lane0, self.n_lanes = traces, lane0, n
+        self.tid = self.off = None
+
+    def reset(self, trace_id, start_offset):
+        self.tid, self.off = trace_id.numpy(), start_offset.numpy()
+
+    def step_random(self, n_steps, seed, out=None):
+        assert n_steps == V and seed == SEED
+        obs, rew = _rollout(self.lane0, self.n_lanes, self.traces, self.tid, self.off)
+        out["obs"].copy_(torch.from_numpy(obs)); out["reward"].copy_(torch.from_numpy(rew))
+        out["done"].fill_(0)
+        return out
 
 
 def _traces():
@@ -53,24 +90,26 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, ROOT)
-    from abrsimulator_amd.sharding import ObsRewardGather, shard_range, unshard_lanes
+    import abrsimulator_amd as A
+    from abrsimulator_amd.sharding import ShardedABREnv, shard_range
+    traces = _traces()
     lane0, n = shard_range(TOTAL, world, rank)
-    counts = [shard_range(TOTAL, world, r)[1] for r in range(world)]
-    nmax = max(counts)
-    obs, rew = _rollout(lane0, n, _traces())
-    # pad the lane axis to the largest shard (all_gather needs equal shapes)
-    po = np.zeros((V, 3, nmax), np.float32); po[..., :n] = obs
-    pr = np.zeros((V, nmax), np.float32); pr[..., :n] = rew
-    g = ObsRewardGather((V, 3, nmax), (V, nmax), "cpu")
-    send = torch.cat([torch.from_numpy(po).reshape(-1), torch.from_numpy(pr).reshape(-1)])
-    go, gr = g.gather(0, send)                      # ONE collective for (obs, reward)
-    g.finish()
-    assert g.n_collectives == 1
-    full_o = unshard_lanes(go, counts).numpy()
-    full_r = unshard_lanes(gr, counts).numpy()
+    sh = ShardedABREnv(None, None, A.NetworkInfo(1.0, traces), total_lanes=TOTAL, fuse=V, device="cpu",
+                       env=OracleShardEnv(traces, lane0, n))
+    assert (sh.lane0, sh.n_lanes, sh.world, sh.rank) == (lane0, n, world, rank) and sum(sh.counts) == TOTAL
+    sh.reset()                                      # the global lane -> (trace, offset) map
+    st1 = sh.step_random(V, SEED)                   # ONE collective for (obs, reward) per launch ...
+    st2 = sh.step_random(V, SEED)                   # ... double-buffered: the second launch's slab is another one
+    sh.finish()
+    assert sh.n_collectives == 2
+    full_o, full_r = st1.unsharded()
+    o2, r2 = st2.unsharded()
+    assert torch.equal(full_o, o2) and torch.equal(full_r, r2)
+    loc = st1.local
+    assert loc["obs"].shape == (V, 8, n) and loc["reward"].shape == (V, n)
     if rank == 0:
-        np.save(out + "_o.npy", full_o)
-        np.save(out + "_r.npy", full_r)
+        np.save(out + "_o.npy", full_o.numpy())
+        np.save(out + "_r.npy", full_r.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,12 +128,36 @@ def test_shard_range_partitions_exactly():
 
 @pytest.mark.parametrize("world", [2, 8])     # 8 = the widest run the driver launches (101 lanes: uneven shards of 13 and 12)
 def test_gather_over_ranks_equals_unsharded(tmp_path, world):
+    """N ranks through the package's ShardedABREnv == the unsharded rollout, lane for lane: the gathered final observation
+    [8, total] and rewards [V, total]."""
     out = str(tmp_path / "g")
     port = _free_port()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     full_o, full_r = np.load(out + "_o.npy"), np.load(out + "_r.npy")
     ref_o, ref_r = _rollout(0, TOTAL, _traces())
-    assert np.array_equal(full_o, ref_o) and np.array_equal(full_r, ref_r)
+    assert full_o.shape == (8, TOTAL) and full_r.shape == (V, TOTAL)
+    assert np.array_equal(full_o, ref_o[V - 1]) and np.array_equal(full_r, ref_r)
+
+
+def test_sharded_env_without_a_process_group_is_the_whole_job():
+    """No process group: one rank holds every lane, no collective is issued, the launch's outputs are the local ones."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import abrsimulator_amd as A
+    from abrsimulator_amd.sharding import ShardedABREnv
+    traces = _traces()
+    sh = ShardedABREnv(None, None, A.NetworkInfo(1.0, traces), total_lanes=TOTAL, fuse=V, device="cpu",
+                       env=OracleShardEnv(traces, 0, TOTAL))
+    assert (sh.lane0, sh.n_lanes, sh.world, sh.counts) == (0, TOTAL, 1, [TOTAL])
+    sh.reset()
+    st = sh.step_random(V, SEED)
+    ref_o, ref_r = _rollout(0, TOTAL, traces)
+    assert np.array_equal(st.local["obs"].numpy(), ref_o) and np.array_equal(st.local["reward"].numpy(), ref_r)
+    assert sh.n_collectives == 0
+    with pytest.raises(RuntimeError):
+        st.gathered()
+    with pytest.raises(ValueError):
+        ShardedABREnv(None, None, A.NetworkInfo(1.0, traces), fuse=V, device="cpu", env=OracleShardEnv(traces, 0, 4))
 
 
 def test_xcd_aware_lane_assignment():

@@ -10,7 +10,7 @@ if [ "$1" != "skip-tests" ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "ring3 or FUSED or rollout or timeout or degenerate" > $O/ab_ring_tests.log 2>&1 || { tail -30 $O/ab_ring_tests.log; exit 1; }
   tail -3 $O/ab_ring_tests.log
 fi
-S="--no-cpu-baseline --no-secondary --no-strong"
+S="--no-cpu-baseline --no-secondary --no-strong --no-sustained --no-mpc-rollout --no-single-step"
 for r in 1 2 3; do
   for I in split3 ring3; do timeout -k 10 120 python bench.py --impl $I --steps 1920 --warmup 192 $S 2>/dev/null | line; done
 done 2>&1 | tee $O/ab_ring_fuse48.txt
