@@ -512,7 +512,7 @@ ABR_HD bool lanej_gate_possible(double buf, bool su, bool be, int32_t n_dl, cons
     return !su && !be && !t.per_lane_speed && (buf + t.L) - (double)n_dl * t.sd >= t.max_buffer - 1.0e-6;
 }
 ABR_HD bool lanej_predict_next_call(double buf, int32_t k, int32_t n_dl, int32_t avail_next, const Tables &t,
-                                    int32_t &k_next) {
+                                    int32_t &k_next, double *buf_next = nullptr) {
     const int32_t mt = t.max_ticks;
     double b = buf;
     int32_t a = 0;
@@ -544,6 +544,7 @@ ABR_HD bool lanej_predict_next_call(double buf, int32_t k, int32_t n_dl, int32_t
         }
     }
     k_next = k;
+    if (buf_next) *buf_next = b;               // buffer_level at that call site (the lane is still playing: b > 0)
     return true;
 }
 

@@ -14,7 +14,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("ABR_ROUND_TAG", "r04")
+TAG = os.environ.get("ABR_ROUND_TAG", "r05")
 ENV_KERNEL = "env_split3_kernel<2>"
 MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
 LANES, FUSE = 65536, 48
@@ -58,9 +58,9 @@ def stage(O):
 def collect():
     G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
     s = json.load(open(os.path.join(G, "summary.json")))
-    for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "sweeps.txt",
-                "role_stamps.txt", "role_stamps_split3.txt", "async_role_stats.txt", "mpc_phase_stamps.txt",
-                "mpc_sq_counters.txt"):
+    for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "bench_env_mpc_mixed.json",
+                "sweeps.txt", "role_stamps_split.txt", "role_stamps_split3.txt", "role_stamps_ring3.txt", "async_role_stats.txt",
+                "mpc_phase_stamps.txt", "mpc_sq_counters.txt", "gpu_fuzz.json"):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
     for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),
@@ -68,6 +68,8 @@ def collect():
         fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # (earlier runs of the round leave theirs behind)
         if fs:
             shutil.copy(fs[-1], os.path.join(P, f"{TAG}_{dst}"))
+    if os.path.exists(os.path.join(G, "soak.jsonl")):
+        shutil.copy(os.path.join(G, "soak.jsonl"), os.path.join(P, f"{TAG}_soak_parity.jsonl"))
     keys = [k + t for t, _ in ENV_RUNS for k in ("fetch_", "write_")] + ["fetch_mpc", "write_mpc"]
     json.dump({k: s[k] for k in keys}, open(os.path.join(P, f"{TAG}_hbm_pmc_summary.json"), "w"), indent=1)
     # ---- HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read) ----

@@ -91,6 +91,8 @@ struct RingPS {                          // P -> S, slot = P's iteration % kRing
 };
 struct RingFb {                          // P's position after its latest iteration, per lane; seq: corrections posted,
     int32_t step[64], k[64], chunk[64], ep[64], alive[64], seq[64];      // seq: count << 8 | slot of the record << 1 | alive
+    double buf[64];                      // buffer_level and start_up | buffer_empty << 1 at that call site: what D needs to
+    int32_t pf[64];                      // compute EXACTLY where a download gated by buffer_full starts (lanej_predict_next_call)
 };
 struct RingCtl {
     int32_t d_pub;        // D: records published
@@ -172,6 +174,19 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
     DVars v;
     role_d_begin(v, p);
     int32_t seen_seq = 0, seen_total = 0, polls = 0;
+    // An APPROXIMATE copy of the player's buffer_level and start_up / buffer_empty flags at the call site of d_step, carried
+    // in float32 by D itself: D runs ahead of P, so P's state is not there when D needs to know whether buffer_full can
+    // gate the download after this one (Simulator.py:143-145).  It only DETECTS that (margin 0.05 s, far above its drift);
+    // when it does, D waits for P to catch up -- lock-step for that one iteration, as the barrier kernels are always --
+    // and computes the exact call site from P's exact state (lanej_predict_next_call).  A wrong guess costs time, never
+    // a result: P validates every download's start tick.
+    float ab = 0.0f;
+    bool asu = true, abe = true;
+    if (i < p.n_lanes) {
+        const uint8_t f0 = p.flags[i];
+        ab = (float)p.buf[i]; asu = (f0 & kFlagStartUp) != 0; abe = (f0 & kFlagBufEmpty) != 0;
+    }
+    const float Lf = (float)tb.L, sdf = (float)tb.sd, maxf = (float)tb.max_buffer, sulf = (float)tb.start_up_length;
     ABR_STAMP(0);
     for (int32_t t = 0;; t++) {
         // ---- space: slot t % K is free once P has consumed record t - K ----
@@ -204,6 +219,8 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
                 } else {
                     v.d_alive = true; v.d_step = fb.step[l]; v.d_k = fb.k[l]; v.d_chunk = fb.chunk[l]; v.d_ep = fb.ep[l];
                     v.cur.j = m.snap_j[r][l]; v.cur.tpos = m.snap_tpos[r][l];
+                    const int32_t pf = fb.pf[l];
+                    ab = (float)fb.buf[l]; asu = pf & 1; abe = pf & 2;       // the player's word for its state there, too
                 }
             }
         }
@@ -228,6 +245,8 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
         // ---- the download of step d_step, started at its (predicted) call site ----
         const int cb = t & (kRingK - 1);
         int32_t flags = 0;
+        bool hot = false;
+        int32_t hot_k = 0, hot_ndl = 0, hot_avail = 0, hot_step = -1;
         if (v.d_alive && v.d_step < n_total) {
             m.snap_j[cb][l] = v.cur.j; m.snap_tpos[cb][l] = v.cur.tpos;
             const abrx::StepStart st = abrx::lanej_begin_step(v.cur, tb, v.d_k, v.d_chunk);
@@ -258,6 +277,22 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
             // ---- where the NEXT download starts, if nothing gates it ----
             if (!d.hit) v.d_alive = false;           // bad action or max_ticks: the player retires the lane
             else {
+                hot_k = v.d_k; hot_ndl = d.n_dl; hot_avail = st.avail_next; hot_step = v.d_step;
+                // can buffer_full gate the NEXT download?  (the approximate state, before it moves on)
+                hot = !asu && !abe && !tb.per_lane_speed && v.d_chunk + 1 < V &&
+                      (ab + Lf) - (float)d.n_dl * sdf >= maxf - 0.05f;
+                // the approximate state at the next call site: what lanej_after_download + lanej_wait_call do to it
+                {
+                    float b;
+                    bool play = true;
+                    if (asu) { b = ab + Lf; asu = b < sulf; play = !asu; }          // start-up: nothing drains (:137-138,:201)
+                    else if (abe) b = Lf;                                            // rebuffering: 0 + L (:170,:194)
+                    else { const float bc = ab - (float)(d.n_dl - 1) * sdf; b = bc <= 0.0f ? Lf : bc + Lf - sdf; }
+                    abe = false;
+                    const int32_t w = st.avail_next - (v.d_k + d.n_dl);
+                    if (play && w > 0) { b -= (float)w * sdf; if (b <= 0.0f) { b = 0.0f; abe = true; } }
+                    ab = b;
+                }
                 v.d_step++;
                 v.d_chunk++;
                 v.d_k = max(v.d_k + d.n_dl, st.avail_next);     // completing tick + 1, or availability (:143)
@@ -265,6 +300,7 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
                     if (p.auto_reset) {            // a fresh episode: clock, cursor and chunk ids restart
                         v.d_chunk = 0; v.d_ep++; v.d_k = tb.avail_tick[0];
                         abrx::cursor_init(v.cur, v.offset0);
+                        ab = 0.0f; asu = true; abe = true;
                     } else v.d_alive = false;
                 }
                 // a call site at or past max_ticks never happens (the player times the lane out)
@@ -273,6 +309,32 @@ __device__ __forceinline__ void ring_d_loop(const EnvParams &p, RingDP &m, RingF
             m.post_j[cb][l] = v.cur.j; m.post_tpos[cb][l] = v.cur.tpos;
         }
         m.flags[cb][l] = flags;
+        // ---- buffer_full in reach for some lane: lock-step for this one iteration ----
+        if (__any(hot)) {
+            // P has consumed every record published so far (p_pub == t) <=> it stands at the call site of the download a lane
+            // in step with the wave has just finished, and its published state is complete (it waits for record t now)
+            for (;;) {
+                const int32_t ab_ = ring_ld(&ctl.abort);
+                const RingP ps = ring_ld_p(ctl);
+                if (ps.done | ab_) break;
+                if (ps.p_pub >= t) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > kRingWatchdog) { ring_publish(&ctl.abort, 1); break; }
+            }
+            ABR_STAMP(6);
+            if (hot && v.d_alive && fb.step[l] == hot_step && fb.k[l] == hot_k && fb.alive[l]) {
+                const int32_t pf = fb.pf[l];
+                const double pbuf = fb.buf[l];
+                int32_t kn;
+                double bn;
+                if (abrx::lanej_gate_possible(pbuf, pf & 1, pf & 2, hot_ndl, tb) &&
+                    abrx::lanej_predict_next_call(pbuf, hot_k, hot_ndl, hot_avail, tb, kn, &bn)) {
+                    v.d_k = kn;
+                    ab = (float)bn; asu = false; abe = false;
+                    if (kn >= tb.max_ticks) v.d_alive = false;
+                }
+            }
+        }
         ring_publish(&ctl.d_pub, t + 1);
         ABR_STAMP(4);
     }
@@ -368,6 +430,7 @@ __device__ __forceinline__ void ring_p_loop(const EnvParams &p, RingDP &m, RingP
         // ---- where this lane is now: the correction's payload, S's bound for drawing ahead, D's resynchronisation ----
         const bool more = v.b_alive && v.b_step < n_total;
         fb.step[l] = v.b_step; fb.k[l] = s.k; fb.chunk[l] = s.chunk_id; fb.ep[l] = v.episode_no; fb.alive[l] = more ? 1 : 0;
+        fb.buf[l] = s.buf; fb.pf[l] = (s.su ? 1 : 0) | (s.be ? 2 : 0);
         // ONE word per correction: count, slot of the record it is about, alive -- read atomically by D.  (step, k, chunk,
         // ep above are the lane's position, which a rejected record did not move: the same values as an iteration ago)
         ABR_LDS_ORDER();

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import abrsimulator_amd as A  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from test_lane_jump_cpu import _random_config  # noqa: E402
-from helpers import oracle_rewards  # noqa: E402
+from helpers import DIAG_IMPLS, diag_lib, oracle_rewards  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
@@ -38,8 +38,8 @@ for seed in range(n_seeds):
     off = np.array([rng.integers(0, lens[t]) for t in tid], np.int32)
     actions = rng.integers(0, B, (N, V)).astype(np.int32)
     feature = ["plain", "lane_speeds", "schedule", "vbr", "schedule+vbr"][seed % 5]
-    impl = ["split3", "split", "jump", "async"][(seed // 5) % 4]
-    fused = (seed // 20) % 2 == 1 or impl == "async"    # one abr_env_step_script call instead of V abr_env_step calls
+    impl = ["split3", "split", "jump", "async", "ring3"][(seed // 5) % 5]    # async / ring3: the diagnostic build (rejected pipelines)
+    fused = (seed // 25) % 2 == 1 or impl in ("async", "ring3")    # one abr_env_step_script call instead of V abr_env_step calls
     speeds, br = None, None
     if "lane_speeds" in feature:
         speeds = rng.choice([0.6, 0.8, 1.0, 1.25, 1.7, 0.9173], N)
@@ -55,7 +55,8 @@ for seed in range(n_seeds):
     mpd = A.MPD(V, meta["chunk_length"], meta["max_buffer"], meta["start_up_length"], chunks)
     sp = meta["speed"] if speeds is None else torch.from_numpy(speeds if speeds.ndim == 1 else speeds.T.copy())
     env = A.BatchedABREnv(mpd, A.QOEMetric(*meta["weights"]), A.NetworkInfo(meta["interval"], traces), N,
-                          speed=sp, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
+                          speed=sp, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000,
+                          library=diag_lib() if impl in DIAG_IMPLS else None)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
     acts = torch.from_numpy(actions).cuda()
     if fused:

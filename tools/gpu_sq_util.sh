@@ -10,7 +10,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD 
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
            "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-strong --steps 480 --warmup 48 "$@" > $O/g$i.log 2>&1 || echo "group $i failed"
+  rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-strong --no-sustained --no-mpc-rollout --no-single-step --steps 480 --warmup 48 "$@" > $O/g$i.log 2>&1 || echo "group $i failed"
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -29,5 +29,8 @@ for k, d in agg.items():
     if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
         print("  wait fraction of wave-cycles: %.3f" % (m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]))
     if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
-        print("  VALU issue utilisation (4 cycles x instr / SIMD / kernel cycles): %.3f" % (4 * m["SQ_INSTS_VALU"] / 1024 / m["GRBM_GUI_ACTIVE"]))
+        # GRBM_GUI_ACTIVE is reported SUMMED over the 8 XCDs (round 4 divided by the sum and printed 0.109 for K3 where the
+        # kernel fills 0.90 of its issue slots): kernel cycles = GRBM_GUI_ACTIVE / 8
+        print("  VALU issue utilisation (4 cycles x instr / SIMD / kernel cycles, kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs): %.3f"
+              % (4 * m["SQ_INSTS_VALU"] / 1024 / (m["GRBM_GUI_ACTIVE"] / 8.0)))
 PY

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import abrsimulator_amd as A  # noqa: E402
-from helpers import oracle_rewards  # noqa: E402
+from helpers import DIAG_IMPLS, diag_lib, oracle_rewards  # noqa: E402
 import bench  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
@@ -28,7 +28,8 @@ V, seed = bench.V, 20260404
 traces = bench.synth_traces(mixed)
 tid, off = bench.lane_assignment(0, N, traces)
 env = A.BatchedABREnv(A.MPD(V, bench.L, bench.MAX_BUFFER, bench.START_UP, A.Chunk(bench.LADDER)),
-                      A.QOEMetric(*bench.WEIGHTS), A.NetworkInfo(bench.INTERVAL, traces), N, impl=impl)
+                      A.QOEMetric(*bench.WEIGHTS), A.NetworkInfo(bench.INTERVAL, traces), N, impl=impl,
+                      library=diag_lib() if impl in DIAG_IMPLS else None)
 env.reset(torch.from_numpy(tid), torch.from_numpy(off))
 t0 = time.perf_counter()
 out = env.step_random(V, seed, out=dict(obs=None, reward=torch.empty(V, N, dtype=torch.float32, device="cuda"),
