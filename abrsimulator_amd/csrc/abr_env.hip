@@ -5,9 +5,9 @@
 //         tick loop's float64 sequences advanced in exact closed form (abr_lane_jump.h,
 //         abr_exact_jump.h); MODE 0 reset, 1 step, 2 fused random-policy rollout, 3 fused scripted rollout
 //   K1    env_split3_kernel<MODE>   the same lane functions on three waves per 64 lanes (download / player /
-//         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes lanes -- for launches of more than
-//         one decision; a single decision per launch goes to env_jump_kernel at every size
-//   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to kSplitMaxLanes lanes
+//         service; abr_env_roles.h): what impl 3 (auto) runs up to kSplit3MaxLanes (65 536) lanes -- for launches of more
+//         than one decision; a single decision per launch goes to env_jump_kernel at every size
+//   K1    env_split_kernel<MODE>    ... on two waves per 64 lanes (download / player): up to kSplitMaxLanes (131 072) lanes
 //   K1/K2 env_advance_kernel<MODE>  the same, one loop trip per 0.01 s tick (cross-check)
 //   K3    mpc_select_kernel<H, B, WVM>   mpc.py:81-93,104-186   harmonic predictor (mpc_predict_kernel ahead of it when the
 //         caller provides scratch) + exhaustive B^H: B^2 threads per lane; tables in LDS, depth-first enumeration with
@@ -1088,13 +1088,14 @@ extern "C" int abr_env_set_lane_id_base(abr_env *env, int64_t base) {
 
 static inline unsigned grid64(int64_t n) { return (unsigned)((n + 63) / 64); }
 
-// Which kernel serves which size (same box, fused 48, profiles/r04_sweeps.txt): the three-wave role split while all its
-// waves are resident (3 x 1 024 waves at 65 536 lanes: 9.2e9 env-steps/s against 8.1e9 two-wave and 7.4e9 one thread per
-// lane); the two-wave role split up to 98 304 lanes (8.6e9 against 7.4e9 at 81 920; 8.8e9 against 8.7e9 at 98 304); one
-// thread per lane above (1.01e10 / 1.15e10 / 1.35e10 at 114 688 / 131 072 / 196 608 against 1.02e10 / 1.16e10 / 1.12e10):
-// it then has two or more waves per SIMD of its own and no barrier.
+// Which kernel serves which size (same box, fused 48, round 5: profiles/r05_sweep_impl.txt -- the role-split kernels gained
+// 18 % from the exact call-site prediction, which moved the crossover up): the three-wave role split while all its waves are
+// resident (3 x 1 024 waves at 65 536 lanes: 1.15e10 env-steps/s against 1.01e10 two-wave and 7.7e9 one thread per lane); the
+// two-wave role split while all ITS waves are resident (2 x 2 048 waves at 131 072 lanes = four per SIMD: 1.39e10 against
+// 1.24e10; 1.18e10 / 1.09e10 at 114 688, 1.02e10 / 9.3e9 at 98 304); one thread per lane above (1.22e10 against 1.11e10 at
+// 163 840, 1.55e10 against 1.28e10 at 262 144): it then has three or more waves per SIMD of its own and no barrier.
 constexpr int64_t kSplit3MaxLanes = 65536;
-constexpr int64_t kSplitMaxLanes = 98304;
+constexpr int64_t kSplitMaxLanes = 131072;
 // The asynchronous pipeline (abr_env_async.h, impl 4) lost to the role-split kernels on MI355X (714 against 418 us
 // per launch at 65 536 lanes, profiles/r03_async_*) and `auto` never picked it: the product library is built
 // without it.  `make libabr_hip_async.so` (-DABR_WITH_ASYNC) keeps it selectable for the parity tests and records.

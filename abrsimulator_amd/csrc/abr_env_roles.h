@@ -2,7 +2,7 @@
 // decision, one iteration behind the previous role.  Included by abr_env.hip.
 //
 //   env_split3_kernel  D | P | S   three waves (impl 5; what impl 3 = auto runs up to kSplit3MaxLanes lanes)
-//   env_split_kernel   D | P+S     two waves   (impl 2; up to kSplitMaxLanes lanes)
+//   env_split_kernel   D | P+S     two waves   (impl 2; what auto runs from 65 537 up to kSplitMaxLanes = 131 072 lanes)
 //
 //   D  download  a pure function of (call-site tick, trace cursor, target size): Simulator.py:152-163
 //   P  player    buffer_level / play_time / counters over the download's ticks, the completing tick, the wait for the
@@ -88,6 +88,8 @@ __device__ __forceinline__ void lds_writes_done() {
 // Why: with ONE loop for all roles every loop-invariant uniform value any role needs -- some 130 scalar registers of
 // pointers and constants -- would be live across the whole loop and spill; re-reading the block behind a compiler-only
 // fence keeps each role's scalar loads inside that role's part of the iteration (a dozen s_load per iteration).
+// CONTRACT: `EnvParams p` must stay the FIRST by-value argument of env_split3_kernel and env_split_kernel (the block is read
+// from offset 0 of the kernarg segment); both kernels check it against their own copy in the diagnostic stamps build.
 __device__ __forceinline__ const EnvParams &fresh_params() {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
@@ -258,6 +260,8 @@ __device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, const ab
         if (v.issued_step == v.d_step) { v.cur.j = v.snap_j; v.cur.tpos = v.snap_tpos; }
         v.issued_step = -1;
     } else if (v.d_alive && v.issued_ndl > 0 && v.d_chunk > 0) {
+        // (Having the PLAYER flag "within chunk_length of max_buffer" in a spare bit of fb_alive, so that this wave reads
+        // nothing more in the common case, lost 0.8 %: the player wave is as critical as this one.  profiles/r05_experiments_not_kept.txt)
         // The record issued in iteration t started where the player really was, and the player's buffer at that call site is
         // known now: if buffer_full is in reach at the completing tick, compute EXACTLY where the next download -- the one
         // this iteration is about to start -- begins, instead of speculating "not gated" and repeating it.  (A lane whose
@@ -671,7 +675,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 }
 
 // =====================================================================================================================
-// Two-wave form: the player wave runs the service tail itself, one iteration behind D (65 537 - 131 072 lanes)
+// Two-wave form: the player wave runs the service tail itself, one iteration behind D (auto: 65 537 - 131 072 lanes,
+// kSplitMaxLanes in abr_env.hip: as long as its 2 waves per 64 lanes are all resident, four per SIMD)
 // =====================================================================================================================
 struct P2Vars {
     PVars pv;

@@ -176,7 +176,7 @@ int abr_env_notify_restore(abr_env *env);
  * workgroup; 0 = event-driven, one thread per lane; 1 = one loop trip per 0.01 s tick;
  * 5 = as 2 with a third wave per 64 lanes for the service tail of a decision (bandwidth = size /
  * time, history, reward, observation, episode end);
- * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 98 304 lanes,
+ * 3 (default) = whichever is fastest at this size: 5 up to 65 536 lanes, 2 up to 131 072 lanes,
  * 0 above -- and 0 at every size for launches of ONE decision (abr_env_step, the per-decision
  * launches of abr_env_step_mpc, a fused call with n_steps == 1).
  * 0, 2 and 5 produce identical state and outputs in every case (the workspace is interchangeable between them, also
@@ -227,7 +227,7 @@ int abr_env_step(abr_env *env, const int32_t *actions_dev, float *obs_out_dev,
  * Outputs (all nullable) are [n_steps][...] slabs: obs [n_steps][ABR_OBS_DIM][n_lanes],
  * reward/done/actions [n_steps][n_lanes].  Lane state is read and written once per call.  Under the one-thread-per-lane
  * kernels (impl 0) lanes progress independently; the role-split kernels (impl 2 / 5) meet at ONE workgroup barrier per
- * decision (64 lanes, two or three waves), which is what `auto` prefers up to 98 304 lanes.
+ * decision (64 lanes, two or three waves), which is what `auto` prefers up to 131 072 lanes.
  */
 int abr_env_step_random(abr_env *env, int32_t n_steps, uint64_t seed, float *obs_out_dev,
                         float *reward_out_dev, uint8_t *done_out_dev, int32_t *actions_out_dev,

@@ -279,7 +279,7 @@ def test_async_falls_back_with_per_lane_speeds():
 
 def test_auto_resolves_to_the_measured_fastest():
     """`auto` is a measured choice: for fused rollouts the three-wave role-split kernel up to
-    65 536 lanes, the two-wave one up to 98 304, one thread per lane above; for launches of ONE decision
+    65 536 lanes, the two-wave one up to 131 072, one thread per lane above; for launches of ONE decision
     (step, the K1 launches of step_mpc, a fused call of one step) one thread per lane at every size;
     the asynchronous pipeline is not in the product library at all."""
     rng = np.random.default_rng(6)
@@ -303,7 +303,9 @@ def test_auto_resolves_to_the_measured_fastest():
     assert torch.equal(one["obs"], two["obs"]) and torch.equal(one["reward"], two["reward"])
     env = make_env(BENCH_META, traces, 65537)
     assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "jump"
-    env = make_env(BENCH_META, traces, 98305)
+    env = make_env(BENCH_META, traces, 131072)
+    assert env.effective_impl(fused=True) == "split" and env.effective_impl(fused=False) == "jump"
+    env = make_env(BENCH_META, traces, 131073)
     assert env.effective_impl(fused=True) == "jump" and env.effective_impl(fused=False) == "jump"
     import abrsimulator_amd as A
     _lib = A._lib.lib()
