@@ -641,6 +641,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __shared__ ActRing ring;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
+#ifdef ABR_SPLIT_STAMPS
+    if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
+#endif
     __shared__ RolePark3 park;
     // The download wave is the critical one; priority outranks age in the SIMD's issue arbitration, so its instructions
     // go first whenever they are ready (+2.8 %, profiles/r03_ab_lds_staging.txt (4)); the ORDER D > P > S is worth 8 %
@@ -831,6 +834,9 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     __shared__ SplitMail m;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
+#ifdef ABR_SPLIT_STAMPS
+    if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
+#endif
     __shared__ RolePark2 park;
     DVars dv;                          // as in env_split3_kernel: D's variables in registers, the player's through LDS
     role_d_begin(dv, p);

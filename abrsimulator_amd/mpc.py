@@ -95,6 +95,13 @@ class BatchedMPCController:
         c.startup_weight = float(self.qoe.startup_weight)
         return c
 
+    def _bind_key(self, n_lanes):
+        """Everything the bound config / options depend on: a change of any of it -- also an in-place change of the MPD's
+        chunk_length or max_buffer, which config() reads -- rebinds on the next select."""
+        return (int(n_lanes), self._tables_for, self.horizon, self.clip_horizon, self.method, self.utility,
+                float(self.mpd.chunk_length), float(self.mpd.max_buffer),
+                float(self.qoe.variance_weight), float(self.qoe.rebuffer_weight), float(self.qoe.startup_weight))
+
     def next_bitrate(self, want_details=False):
         """mpc.py:181-186, batched: returns int32 [N] bitrate indices."""
         ci = self.player.get_next_chunk_info()
@@ -115,8 +122,7 @@ class BatchedMPCController:
                 raise TypeError(f"chunk-info tensors must be {dt} on the GPU")
         # the config / options structs and the predictor's scratch are bound once per (lane count, tables, weights,
         # method): a select is then the two kernel launches and nothing else on the host (BoundOut's counterpart)
-        key = (N, self._tables_for, self.horizon, self.clip_horizon, self.method, self.utility,
-               float(self.qoe.variance_weight), float(self.qoe.rebuffer_weight), float(self.qoe.startup_weight))
+        key = self._bind_key(N)
         if self._bound is None or self._bound[0] != key:
             cfg = self.config()
             opt = _lib.MpcOptions()

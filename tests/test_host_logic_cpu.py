@@ -83,3 +83,34 @@ def test_lane_assignment_is_a_function_of_the_global_lane_id():
         assert np.array_equal(np.concatenate([p[0] for p in parts]), tid)
         assert np.array_equal(np.concatenate([p[1] for p in parts]), off)
     assert (off < np.asarray(lens)[tid]).all() and off.min() >= 0
+
+
+def test_mpc_binding_follows_in_place_changes_of_the_mpd():
+    """The controller binds its config struct once per (lanes, tables, horizon, method, weights, chunk_length, max_buffer):
+    an in-place change of the MPD's max_buffer or chunk_length (mutable dataclass; config() re-reads both, and
+    env.step_mpc() calls config() fresh) must rebind on the next select, not be ignored until update_mpd()."""
+    import abrsimulator_amd as A
+
+    class Player:
+        def __init__(self):
+            self.mpd = A.MPD(8, 4.0, 20.0, 8.0, A.Chunk([1.0, 2.0, 3.0]))
+            self.qoe = A.QOEMetric(4.3, 1.0, 0.0)
+
+        def get_mpd(self):
+            return self.mpd
+
+        def get_qoe_metric(self):
+            return self.qoe
+
+    p = Player()
+    ctl = A.BatchedMPCController(p, horizon=3, device="cpu")
+    ctl._tables_for = p.mpd                       # (the tables themselves live on the GPU: not built here)
+    k0 = ctl._bind_key(16)
+    assert ctl._bind_key(16) == k0 and ctl._bind_key(17) != k0
+    p.mpd.max_buffer = 12.0
+    k1 = ctl._bind_key(16)
+    assert k1 != k0
+    p.mpd.chunk_length = 2.0
+    assert ctl._bind_key(16) != k1
+    p.qoe.rebuffer_weight = 1.0
+    assert ctl._bind_key(16)[-2] == 1.0
