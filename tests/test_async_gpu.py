@@ -341,3 +341,51 @@ def test_per_chunk_ladders_on_the_async_pipeline(oracle):
         for k in ("obs", "reward", "done", "actions"):
             assert torch.equal(outs[impl][0][k], outs["async"][0][k]), (impl, k)
         assert torch.equal(outs[impl][1], outs["async"][1])
+
+
+def test_launch_cuts_with_everything_in_between(oracle):
+    """Fused random-policy launches of the three-wave kernel cut anywhere -- on every chunk, on episode ends, on call sites
+    gated by buffer_full -- with whatever can happen between two launches: nothing, another seed, a masked reset, single
+    steps, a scripted launch, another implementation.  The outputs and the state equal the one-thread-per-lane kernel's.
+    (Written for round 5's cross-launch stash of the first download -- measured at 1 us per launch and not kept,
+    profiles/r05_experiments_not_kept.txt, r05_stash.patch -- and kept as a test of the hand-over between launches.)"""
+    rng = np.random.default_rng(17)
+    traces = _bench_like(rng, n_traces=8)
+    N = 777
+    meta = dict(BENCH_META, video_length=6, max_buffer=9.0)          # short episodes: the cut falls on every chunk, also on
+    tid = rng.integers(0, len(traces), N).astype(np.int32)            # episode ends; a small buffer: gated cuts
+    off = np.array([rng.integers(0, len(traces[t])) for t in tid], np.int32)
+    envs = {impl: make_env(meta, traces, N, impl=impl, auto_reset=True, lane_id_base=4242) for impl in ("split3", "jump")}
+    for e in envs.values():
+        e.reset(torch.from_numpy(tid), torch.from_numpy(off))
+    mask = torch.from_numpy((rng.random(N) < 0.4).astype(np.uint8))
+    acts1 = torch.from_numpy(rng.integers(0, 6, N).astype(np.int32)).cuda()
+    script = torch.from_numpy(rng.integers(0, 6, (5, N)).astype(np.int32)).cuda()
+
+    def both(fn):
+        a, b = fn(envs["split3"]), fn(envs["jump"])
+        if isinstance(a, dict):
+            for k in a:
+                if a[k] is not None:
+                    assert torch.equal(a[k], b[k]), k
+        elif isinstance(a, tuple):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        fa, fb = envs["split3"].observe_f64(), envs["jump"].observe_f64()
+        for k in fa:
+            assert torch.equal(fa[k], fb[k]), k
+    for n in (7, 7, 5, 6, 13, 2):                                     # back to back
+        both(lambda e, n=n: e.step_random(n, 31))
+    both(lambda e: e.step_random(7, 32))                              # another seed
+    both(lambda e: e.step_random(7, 32))
+    both(lambda e: (e.reset(torch.from_numpy(tid), torch.from_numpy(off), mask=mask).clone(),))   # some lanes start over
+    both(lambda e: e.step_random(9, 32))
+    both(lambda e: tuple(x.clone() for x in e.step(acts1)))           # single steps move the call site
+    both(lambda e: e.step_random(4, 32))
+    both(lambda e: e.step_script(script))                             # a scripted launch
+    both(lambda e: e.step_random(11, 32))
+    envs["split3"].lib.abr_env_set_impl(envs["split3"]._h, 2)         # the two-wave kernel in between
+    both(lambda e: e.step_random(5, 32))
+    envs["split3"].lib.abr_env_set_impl(envs["split3"]._h, 5)
+    both(lambda e: e.step_random(8, 32))
+    both(lambda e: e.step_random(8, 32))
