@@ -1255,17 +1255,23 @@ extern "C" int abr_env_observe_f64(abr_env *env, double *out_dev, void *stream) 
 
 #ifdef ABR_SPLIT_STAMPS
 extern "C" int abr_debug_read_stamps(unsigned long long *out32, int reset) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc), z, sizeof(z)); }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_st_acc), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc), z, sizeof(z)); }
     return 0;
 }
 #endif
 
 #ifdef ABR_SPLIT_STAMPS
+extern "C" int abr_debug_read_stamps_xcd(unsigned long long *out8x32, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8x32, HIP_SYMBOL(g_st_acc_xcd), 8 * 32 * sizeof(unsigned long long));
+    if (reset) { static unsigned long long z[8 * 32]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_acc_xcd), z, sizeof(z)); }
+    return 0;
+}
 extern "C" int abr_debug_read_wg_times(unsigned long long *out, int n_wg) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), (size_t)n_wg * 10 * sizeof(unsigned long long));
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_t), (size_t)n_wg * 10 * sizeof(unsigned long long));
     return 0;
 }
 #endif

@@ -38,6 +38,17 @@
 #define ABR_OUT(ref, val) ((ref) = (val))
 #endif
 
+// issue priorities of the three roles (s_setprio; A/B knobs: profiles/r03_ab_split3.txt, r05_experiments_not_kept.txt (3))
+#ifndef ABR_PRIO_D
+#define ABR_PRIO_D 2
+#endif
+#ifndef ABR_PRIO_P
+#define ABR_PRIO_P 1
+#endif
+#ifndef ABR_PRIO_S
+#define ABR_PRIO_S 0
+#endif
+
 struct SplitMail {
     // D -> P, double-buffered by iteration parity
     double dl[2][64];
@@ -652,9 +663,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     role_d_begin(dv, p);               // depends on the role); P's and S's go through LDS between iterations
     if (role == 0) ABR_WG_TIME(0);
     ABR_WG_WHERE(role);
-    if (role == 0) __builtin_amdgcn_s_setprio(2);
-    else if (role == 1) { __builtin_amdgcn_s_setprio(1); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
-    else { SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
+    if (role == 0) __builtin_amdgcn_s_setprio(ABR_PRIO_D);
+    else if (role == 1) { __builtin_amdgcn_s_setprio(ABR_PRIO_P); PVars v; role_p3_begin(v, p); p_park(park.p, v); }
+    else { __builtin_amdgcn_s_setprio(ABR_PRIO_S); SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {
             if (t > 0) role_d_validate(dv, m, make_tables(p), t - 1);      // against what P published before the previous barrier

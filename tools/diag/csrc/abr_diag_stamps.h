@@ -12,6 +12,7 @@
 // cycles since that wave's previous stamp to region n, in LDS; the totals go to global memory
 // once, at the end of the kernel (ABR_STAMP_FLUSH); read with abr_debug_read_stamps.
 __device__ unsigned long long g_st_acc[32];
+__device__ unsigned long long g_st_acc_xcd[8][32];     // the same, per XCD (HW_REG_XCC_ID): which region differs where
 __shared__ unsigned long long g_sh_st[3][33];
 #define ABR_STAMP(n)                                                                           \
     do {                                                                                       \
@@ -31,10 +32,14 @@ __shared__ unsigned long long g_sh_st[3][33];
     } while (0)
 #define ABR_STAMP_FLUSH()                                                                      \
     do {                                                                                       \
+        unsigned xcc_f_;                                                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_f_));                  \
         if ((threadIdx.x & 63) == 0)                                                           \
             for (int q_ = 0; q_ < 32; q_++)                                                    \
-                if (g_sh_st[(threadIdx.x >> 6) % 3][q_])                                       \
+                if (g_sh_st[(threadIdx.x >> 6) % 3][q_]) {                                     \
                     atomicAdd(&g_st_acc[q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]);             \
+                    atomicAdd(&g_st_acc_xcd[xcc_f_ & 7][q_], g_sh_st[(threadIdx.x >> 6) % 3][q_]); \
+                }                                                                              \
     } while (0)
 // when each role of each workgroup began and ended (s_memtime): [workgroup][0 = begin, 1 = D end, 2 = P end, 3 = S end]
 // [4 + role]: where that role's wave ran: HW_REG_XCC_ID << 16 | HW_REG_HW_ID (simd_id[5:4] cu_id[11:8] sh_id[12] se_id[15:13])

@@ -28,8 +28,14 @@ rd = env.lib.abr_debug_read_stamps
 rd.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * 32)()
 rd(buf, 1)
+bx = (C.c_ulonglong * 256)()
+if hasattr(env.lib, "abr_debug_read_stamps_xcd"):
+    env.lib.abr_debug_read_stamps_xcd.argtypes = [C.c_void_p, C.c_int]
+    env.lib.abr_debug_read_stamps_xcd(bx, 1)
 env.step_random(48, 1, want_actions=False)
 rd(buf, 1)
+if hasattr(env.lib, "abr_debug_read_stamps_xcd"):
+    env.lib.abr_debug_read_stamps_xcd(bx, 1)
 waves = N // 64
 regions = {1: "D begin_step loads", 2: "D philox", 3: "D download loop", 4: "D publish", 5: "D barrier wait",
            0: "D validate+loop", 9: "P record read", 10: "P drain (download ticks)", 11: "P completing tick",
@@ -43,6 +49,16 @@ if IMPL == "ring3":     # the ring-coupled kernel reuses the slots (abr_env_ring
                     20: "S draws ahead", 22: "S wait: input (P behind)", 21: "S service"})
 for k in sorted(regions):
     print(f"  [{k:2d}] {regions[k]:28s} {buf[k] / waves / 49:9.0f} cycles / wave / iteration")
+
+# the same per XCD: cycles per wave per iteration of every region, one column per XCD (128 workgroups each)
+if hasattr(env.lib, "abr_debug_read_stamps_xcd") and sum(bx) > 0:
+    x = np.array(bx, dtype=np.float64).reshape(8, 32) / (waves / 8.0) / 49.0
+    print("  per XCD (cycles / wave / iteration)      " + "".join(f"  xcd{q}  " for q in range(8)))
+    for k in sorted(regions):
+        if x[:, k].sum() > 0:
+            print(f"  [{k:2d}] {regions[k]:34s}" + "".join(f"{v:8.0f}" for v in x[:, k]))
+    for name, ks in (("D total", (0, 1, 2, 3, 4, 5, 6)), ("P total", (8, 9, 10, 11, 12, 13, 17, 18, 19)), ("S total", (20, 21, 22))):
+        print(f"       {name:34s}" + "".join(f"{x[q, list(ks)].sum():8.0f}" for q in range(8)))
 
 # how long each workgroup lived, and how that depends on what else ran on its waves' SIMDs (diagnostic build).  s_memtime has a
 # different base per XCD, so only differences inside a workgroup mean anything.
