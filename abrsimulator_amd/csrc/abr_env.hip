@@ -750,6 +750,7 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
 // Diagnostic builds only (tools/diag/csrc; `auto` never picks them, the product library does not contain them):
 #ifdef ABR_WITH_RING
 #include "abr_env_ring.h"      // the role pipeline coupled by LDS rings instead of a per-iteration barrier (round 5, impl 6)
+#include "abr_env_pair.h"      // download and player wave in lock-step, the service wave behind a ring (round 5, impl 7)
 #endif
 #ifdef ABR_WITH_ASYNC
 #include "abr_env_async.h"     // the asynchronous pipeline of round 3 (impl 4)
@@ -1013,7 +1014,7 @@ extern "C" int abr_env_has_impl(int32_t impl) {
     case 4: return 1;
 #endif
 #ifdef ABR_WITH_RING
-    case 6: return 1;
+    case 6: case 7: return 1;
 #endif
     default: return 0;
     }
@@ -1023,7 +1024,7 @@ extern "C" int abr_env_has_impl(int32_t impl) {
 // 0 = event-driven, one thread per lane, 1 = tick-by-tick kernels (kept as a cross-check)
 extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
-    if (impl < 0 || impl > 6)
+    if (impl < 0 || impl > 7)
         return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 5 (split3)");
     if (!abr_env_has_impl(impl))
         return fail(ABR_E_UNSUPPORTED, "impl %d (4: the asynchronous pipeline, 6: the ring-coupled role pipeline) is not part of "
@@ -1122,12 +1123,17 @@ static inline int effective_impl(const abr_env *env, bool fused = false) {
     (void)fused;
     return impl;
 }
-static inline bool is_split(int impl) { return impl == 2 || impl == 5 || impl == 6; }
+static inline bool is_split(int impl) { return impl == 2 || impl == 5 || impl == 6 || impl == 7; }
 // launch of the role-split kernels: two waves per 64 lanes (impl 2) or three (impl 5)
 template <int MODE>
 static void launch_split(int impl, const EnvParams &p, const int32_t *actions, float *obs, float *rew, uint8_t *dn,
                          int32_t *acts, int32_t n_steps, uint64_t seed, hipStream_t st) {
 #ifdef ABR_WITH_RING
+    if (impl == 7) {
+        hipLaunchKernelGGL(env_pair3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(192), 0, st, p, actions, obs, rew,
+                           dn, acts, n_steps, seed);
+        return;
+    }
     if (impl == 6) {
         hipLaunchKernelGGL(env_ring3_kernel<MODE>, dim3(grid64(p.n_lanes)), dim3(64 * ABR_RING_WAVES), 0, st, p, actions, obs, rew,
                            dn, acts, n_steps, seed);

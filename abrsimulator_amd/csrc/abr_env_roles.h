@@ -380,9 +380,11 @@ __device__ __forceinline__ void role_p3_begin(PVars &v, const EnvParams &p) {
 
 // Three-wave kernel, before the barrier: the player side of the step D finished in the previous iteration; the
 // finished step goes to S through m2.
-template <int MODE>
-__device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitMail &m, SplitMail2 &m2,
-                                            int32_t n_total, int32_t t) {
+// (M2 / cb2: where the finished step goes for S -- SplitMail2 slot t & 1 under the barrier; a deeper ring in the diagnostic
+// pair kernel, tools/diag/csrc/abr_env_pair.h)
+template <int MODE, class M2>
+__device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitMail &m, M2 &m2,
+                                            int32_t n_total, int32_t t, int cb2) {
     const int l = threadIdx.x & 63;
     const int cb = t & 1, pb = (t + 1) & 1;    // this iteration's / the previous one's slot
     const abrx::Tables tb = make_tables(p);
@@ -396,7 +398,7 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
         if ((fl & kRecValid) && m.step[pb][l] == v.b_step && m.k_start[pb][l] == s.k) {
             const int32_t a = m.action[pb][l];
             meta = kS3Valid | (a & 0xff);
-            m2.step[cb][l] = v.b_step;
+            m2.step[cb2][l] = v.b_step;
             if (fl & kRecBadAct) {
                 meta |= kS3Bad;
                 v.b_alive = false;
@@ -407,10 +409,10 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
                 if (sr.hit) meta |= kS3Hit;
                 if (sr.ended) meta |= kS3Ended;
                 if (sr.timeout) meta |= kS3Timeout;
-                m2.dl[cb][l] = d.dl; m2.n_dl[cb][l] = d.n_dl;
-                m2.nrb_r[cb][l] = s.n_rb; m2.nsu_r[cb][l] = s.n_su;
+                m2.dl[cb2][l] = d.dl; m2.n_dl[cb2][l] = d.n_dl;
+                m2.nrb_r[cb2][l] = s.n_rb; m2.nsu_r[cb2][l] = s.n_su;
                 if (sr.ended || sr.timeout) {
-                    m2.lat[cb][l] = player_latency(p, s);
+                    m2.lat[cb2][l] = player_latency(p, s);
                     if (p.auto_reset && sr.ended) {
                         // re-arm: this step's observation is the new episode's first call site
                         abrx::lanej_init_player(s, tb);
@@ -419,15 +421,15 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
                         if (!abrx::lanej_wait_call(s, tb)) { meta |= kS3Timeout2; v.b_alive = false; }
                     } else v.b_alive = false;
                 }
-                m2.buf[cb][l] = s.buf; m2.k[cb][l] = s.k; m2.nplay_o[cb][l] = s.n_play;
-                m2.nrb_o[cb][l] = s.n_rb; m2.nsu_o[cb][l] = s.n_su;
-                if (speeds) m2.pt[cb][l] = s.pt;
+                m2.buf[cb2][l] = s.buf; m2.k[cb2][l] = s.k; m2.nplay_o[cb2][l] = s.n_play;
+                m2.nrb_o[cb2][l] = s.n_rb; m2.nsu_o[cb2][l] = s.n_su;
+                if (speeds) m2.pt[cb2][l] = s.pt;
             }
             v.b_step++;
         }
     }
     ABR_STAMP(13);
-    m2.meta[cb][l] = meta;
+    m2.meta[cb2][l] = meta;
     player_feedback(m, v, n_total, cb);
     ABR_STAMP(17);
 }
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             role_d_pre<MODE, true>(dv, p, m, &ring, actions, actions_out, n_total, seed, t);
         } else if (role == 1) {
             PVars v; p_unpark(park.p, v, p);
-            role_p3_pre<MODE>(v, p, m, m2, n_total, t);
+            role_p3_pre<MODE>(v, p, m, m2, n_total, t, t & 1);
             p_park(park.p, v);
         } else {
             SVars v; s_unpark(park.s, v);

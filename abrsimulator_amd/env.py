@@ -128,7 +128,7 @@ class BatchedABREnv:
         self._h = h
         if lane_id_base:
             self._check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
-        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4, "split3": 5, "ring3": 6}
+        impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4, "split3": 5, "ring3": 6, "pair3": 7}
         if impl not in impls:
             raise ValueError("impl must be 'auto' (default: the fastest at this size, see effective_impl()), "
                              "'split' / 'split3' (role-split event-driven kernels, two / three waves per 64 lanes), "
@@ -273,7 +273,7 @@ class BatchedABREnv:
         and a fused call with n_steps == 1) -- under 'auto' those resolve to 'jump' at every size (include/abr_env.h)."""
         v = C.c_int32()
         self._check(self.lib.abr_env_get_effective_impl(self._h, int(bool(fused)), C.byref(v)))
-        return {0: "jump", 1: "tick", 2: "split", 4: "async", 5: "split3", 6: "ring3"}[v.value]
+        return {0: "jump", 1: "tick", 2: "split", 4: "async", 5: "split3", 6: "ring3", 7: "pair3"}[v.value]
 
     def step_mpc(self, controller, n_steps: int, out=None, want_obs=True, want_actions=True):
         """n_steps decisions per lane taken by `controller` (a BatchedMPCController whose

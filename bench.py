@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--workload", default="env_random", choices=["env_random", "mpc", "env_mpc"])
     ap.add_argument("--mixed-traces", action="store_true", help="trace lengths 300..3000 (configs[4])")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--impl", default="auto", choices=["auto", "async", "split", "split3", "ring3", "jump", "tick"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "async", "split", "split3", "ring3", "pair3", "jump", "tick"])
     ap.add_argument("--min-timed-steps", type=int, default=960,
                     help="when --steps is smaller than this the timed region of exactly --steps steps is "
                          "repeated (each repeat bracketed by barrier + synchronize) and the MEDIAN repeat "
@@ -334,7 +334,7 @@ def main():
     env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
                           auto_reset=True, lane_id_base=lane0, impl=a.impl)
     env.reset(torch.from_numpy(tid), torch.from_numpy(off))
-    KERNELS = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>", "ring3": "env_ring3_kernel<2>",
+    KERNELS = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>", "ring3": "env_ring3_kernel<2>", "pair3": "env_pair3_kernel<2>",
                "jump": "env_jump_kernel<2>", "tick": "env_advance_kernel<2>"}
     impl = env.effective_impl(fused=True)      # what the library resolves --impl to for fused rollouts
     env_kernel = KERNELS[impl]                 # (re-read below once the decisions per launch are known)

@@ -9,7 +9,7 @@ from oracle.oracle import philox_action  # noqa: E402,F401  (bit-exact numpy twi
 
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIAG_IMPLS = ("async", "ring3")      # pipelines that were measured slower and live in the diagnostic build only
+DIAG_IMPLS = ("async", "ring3", "pair3")      # pipelines that were measured slower and live in the diagnostic build only
 
 
 def diag_lib():

@@ -17,7 +17,7 @@ from helpers import (F64_EXACT, auto_reset_rollout_rewards, golden_rewards, make
 
 pytestmark = pytest.mark.gpu
 
-FUSED_IMPLS = ["async", "ring3", "split3", "split", "jump"]
+FUSED_IMPLS = ["async", "ring3", "pair3", "split3", "split", "jump"]
 
 
 def _obs_expect(rec, s):
@@ -78,7 +78,7 @@ def test_scripted_rollout_random_configurations_against_oracle(oracle, seed):
     steps, bw, fin, _ = oracle.env_batch(cfg, traces, trace_id, offset, actions, max_ticks=4_000_000)
     ref = None
     want_rew = oracle_rewards(steps, fin, actions, meta["weights"], ladder=meta["ladder"])
-    for impl in ("async", "ring3", "split3", "jump"):
+    for impl in ("async", "ring3", "pair3", "split3", "jump"):
         env = make_env(meta, traces, N, impl=impl, max_ticks=int(fin["ticks"].max()) + 1000)
         env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
         out = env.step_script(torch.from_numpy(actions.T.copy()))

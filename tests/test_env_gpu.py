@@ -35,7 +35,7 @@ def _cmp_step(f64, g, s, name):
     assert np.array_equal((fl >> 2) & 1, g["buffer_full"][:, s])
 
 
-IMPLS = ["split", "split3", "ring3", "jump", "tick"]   # role-split (2 / 3 waves per 64 lanes; ring3: three waves coupled by LDS rings), one-thread-per-lane, tick-by-tick cross-check
+IMPLS = ["split", "split3", "ring3", "pair3", "jump", "tick"]   # role-split (2 / 3 waves per 64 lanes; ring3: three waves coupled by LDS rings), one-thread-per-lane, tick-by-tick cross-check
 
 
 @pytest.mark.parametrize("impl", IMPLS)

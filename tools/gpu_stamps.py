@@ -43,6 +43,9 @@ regions = {1: "D begin_step loads", 2: "D philox", 3: "D download loop", 4: "D p
            17: "P feedback", 18: "P barrier wait", 8: "P loop",
            20: "S loop", 21: "S service (split3)", 22: "S barrier wait",
            23: "P idle: up to the drain", 24: "P drain: segments", 25: "P drain: plain tail loop"}
+if IMPL == "pair3":     # download and player wave in lock-step, the service wave behind a ring (abr_env_pair.h)
+    regions.update({5: "D rendezvous wait (P behind)", 18: "P rendezvous wait (D behind)", 19: "P wait: ring full (S behind)",
+                    20: "S draws ahead", 22: "S wait: input (P behind)", 21: "S service"})
 if IMPL == "ring3":     # the ring-coupled kernel reuses the slots (abr_env_ring.h)
     regions.update({0: "D corrections + loop", 5: "D wait: ring full (P behind)", 18: "P wait: input (D behind)",
                     19: "P wait: ring full (S behind)", 13: "P return + hand-off to S", 17: "P position + publish",
