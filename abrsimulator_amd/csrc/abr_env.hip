@@ -1027,7 +1027,7 @@ extern "C" int abr_env_set_impl(abr_env *env, int32_t impl) {
     if (impl < 0 || impl > 7)
         return fail(ABR_E_INVALID, "impl must be 0 (jump), 1 (tick), 2 (split), 3 (auto) or 5 (split3)");
     if (!abr_env_has_impl(impl))
-        return fail(ABR_E_UNSUPPORTED, "impl %d (4: the asynchronous pipeline, 6: the ring-coupled role pipeline) is not part of "
+        return fail(ABR_E_UNSUPPORTED, "impl %d (4: the asynchronous pipeline, 6: the ring-coupled role pipeline, 7: the pair rendezvous) is not part of "
                     "the product library: it is slower than what `auto` selects; the diagnostic build "
                     "tools/diag/lib/libabr_hip_diag.so carries it", impl);
     if (impl == 1 && (env->p.lane_speeds || (env->speeds_dirty && env->pending_speeds)))

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 /* 3: abr_env_has_impl (which implementations THIS build of the library carries: the product answers 0 for the rejected
- * pipelines 4 and 6, which abr_env_set_impl refuses with ABR_E_UNSUPPORTED); under impl 3 (auto) a launch of ONE decision
+ * pipelines 4, 6 and 7, which abr_env_set_impl refuses with ABR_E_UNSUPPORTED); under impl 3 (auto) a launch of ONE decision
  * resolves to 0 at every size (abr_env_get_effective_impl(fused = 0)); ABR_DONE_INTERNAL is reserved for the diagnostic
  * pipelines' watchdogs.  A version-2 host keeps working: nothing it could call changed its signature.
  * 2: abr_env_step_script, abr_env_get_effective_impl, abr_env_notify_restore, impl 5 (three waves per 64
@@ -183,11 +183,12 @@ int abr_env_notify_restore(abr_env *env);
  * mid-episode).  1 is an independent cross-check: it agrees with them on every lane that ends its episode, but it visits
  * ticks in blocks, so a lane that runs into max_ticks (ABR_DONE_TIMEOUT -- build-defined: the reference has no time-out)
  * is frozen at its block boundary: same done bits, different frozen counters in that lane's last observation.
- * 4 (the asynchronous pipeline of round 3) and 6 (the ring-coupled role pipeline of round 5) were measured slower than what
- * 3 selects and are not in the product library: ABR_E_UNSUPPORTED, see abr_env_has_impl. */
+ * 4 (the asynchronous pipeline of round 3), 6 (the ring-coupled role pipeline of round 5) and 7 (round 5: download and player
+ * wave in lock-step through LDS counters, the service wave behind a ring) were measured slower than -- or, 7, within 1 % of --
+ * what 3 selects and are not in the product library: ABR_E_UNSUPPORTED, see abr_env_has_impl. */
 int abr_env_set_impl(abr_env *env, int32_t impl);
 
-/* 1 if this build of the library can run implementation `impl` (0..6), else 0.  The product library: 0, 1, 2, 3, 5. */
+/* 1 if this build of the library can run implementation `impl` (0..7), else 0.  The product library: 0, 1, 2, 3, 5. */
 int abr_env_has_impl(int32_t impl);
 
 /* The implementation (0, 1, 2 or 5; never 3) the handle resolves to right now: fused != 0 for

@@ -177,7 +177,7 @@ def test_product_library_ships_only_selectable_kernels(L):
     refused by the product.  abrsimulator_amd/csrc holds only what libabr_hip.so is built from."""
     blob = open(L.SO_PATH, "rb").read()
     assert b"env_split3_kernel" in blob and b"env_split_kernel" in blob and b"env_jump_kernel" in blob
-    for sym in (b"env_async_kernel", b"env_ring3_kernel", b"g_st_acc", b"g_wg_t", b"g_async_stats", b"jump_fix",
+    for sym in (b"env_async_kernel", b"env_ring3_kernel", b"env_pair3_kernel", b"g_st_acc", b"g_wg_t", b"g_async_stats", b"jump_fix",
                 b"abr_debug_read_stamps", b"abr_debug_read_wg_times"):
         assert sym not in blob, sym
     src = os.path.join(ROOT, "abrsimulator_amd", "csrc")
@@ -192,7 +192,7 @@ def test_product_library_ships_only_selectable_kernels(L):
         if f.endswith(".py"):
             text = open(os.path.join(pkg, f)).read()
             assert "libabr_hip_" not in text and "ASYNC_SO" not in text, f
-    assert L.lib().abr_env_has_impl(4) == 0 and L.lib().abr_env_has_impl(6) == 0 and L.lib().abr_env_has_impl(5) == 1
+    assert [L.lib().abr_env_has_impl(i) for i in range(9)] == [1, 1, 1, 1, 0, 1, 0, 0, 0]
 
 
 def test_env_kernels_have_one_barrier_and_no_calls():
@@ -223,7 +223,7 @@ def test_env_kernels_have_one_barrier_and_no_calls():
         kernels[(k.group(1), int(mode.group(1)))] = body.group(0)
     assert {("split3", 1), ("split3", 2), ("split3", 3), ("split", 1), ("split", 2), ("split", 3),
             ("jump", 0), ("jump", 1), ("jump", 2), ("jump", 3)} <= set(kernels)
-    assert not any("ring3" in n or "async" in n for n in names)         # the product carries no rejected pipeline
+    assert not any("ring3" in n or "pair3" in n or "async" in n for n in names)         # the product carries no rejected pipeline
     for (kind, mode), body in kernels.items():
         assert "s_swappc" not in body and "s_setpc" not in body, (kind, mode)
         if kind in ("split3", "split"):

@@ -309,14 +309,14 @@ def test_auto_resolves_to_the_measured_fastest():
     assert env.effective_impl(fused=True) == "jump" and env.effective_impl(fused=False) == "jump"
     import abrsimulator_amd as A
     _lib = A._lib.lib()
-    for impl_no in (4, 6):                        # the rejected pipelines are refused by the product library ...
+    for impl_no in (4, 6, 7):                     # the rejected pipelines are refused by the product library ...
         assert _lib.abr_env_has_impl(impl_no) == 0
         with pytest.raises(A._lib.AbrError):
             A._lib.check(_lib.abr_env_set_impl(env._h, impl_no), _lib)
     assert all(_lib.abr_env_has_impl(i) == 1 for i in (0, 1, 2, 3, 5))
     from helpers import diag_lib
     diag = A._lib.lib(diag_lib())                 # ... and carried by the diagnostic build, which tests name explicitly
-    assert diag.abr_env_has_impl(4) == 1 and diag.abr_env_has_impl(6) == 1
+    assert diag.abr_env_has_impl(4) == 1 and diag.abr_env_has_impl(6) == 1 and diag.abr_env_has_impl(7) == 1
     with pytest.raises(A._lib.AbrError):          # the package never loads that build by itself
         make_env(BENCH_META, traces, 512, impl="ring3", library=A._lib.SO_PATH)
 
