@@ -510,6 +510,16 @@ def test_bench_rccl_code_path_with_one_rank():
     assert st["value"] > line["value"] and st["collective"].endswith("issued 3x")
 
 
+def test_sharded_env_over_rccl_with_one_rank():
+    """The package's ShardedABREnv over the RCCL backend with a ONE-rank group, in a fresh process: random-policy, scripted and
+    MPC-driven launches, double-buffered slabs, the all-gather on the side stream; gathered == local == an unsharded env."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_rccl_one_rank.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded one-rank RCCL ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_bench_default_line_carries_both_scaling_curves_two_ranks():
     """What the driver's SCALE run launches (bare `bench.py --gpus N`), rehearsed with two gloo ranks on this
     box's one GPU: the headline stays weak scaling at the per-GPU lane count, and the strong-scaling job is
