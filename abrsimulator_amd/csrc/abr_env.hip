@@ -1787,7 +1787,7 @@ static void launch_mpc_b(const MpcParams &p, int T, int D, hipStream_t st) {
     hipLaunchKernelGGL((mpc_select_kernel<H, BC, WVM>), dim3(grid), dim3(threads), lds, st, p, T, D, lpb);
 }
 
-// compile-time rate count for the common ladders (6 and 4 rates) up to horizon 6
+// compile-time rate count for the common ladders (6 and 4 rates with exact-weight variants; 3, 5, 7 and 8 rates) up to horizon 6
 template <int H>
 static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
     if constexpr (H <= 6) {
@@ -1797,6 +1797,14 @@ static void launch_mpc(const MpcParams &p, int T, int D, hipStream_t st) {
         if (p.B == 6) { launch_mpc_b<H, 6, 0>(p, T, D, st); return; }
         if (p.B == 4 && p.wv == 0.0) { launch_mpc_b<H, 4, 2>(p, T, D, st); return; }
         if (p.B == 4) { launch_mpc_b<H, 4, 0>(p, T, D, st); return; }
+#ifndef ABR_MPC_FEW_LADDERS
+        // round 5: the other ladder sizes from 3 to 8 rates get the compile-time rate count too (the generic path
+        // runs 30 - 40 % below the specialised one per combination: profiles/r05_mpc_other_shapes.txt)
+        if (p.B == 5) { launch_mpc_b<H, 5, 0>(p, T, D, st); return; }
+        if (p.B == 3) { launch_mpc_b<H, 3, 0>(p, T, D, st); return; }
+        if (p.B == 8) { launch_mpc_b<H, 8, 0>(p, T, D, st); return; }
+        if (p.B == 7) { launch_mpc_b<H, 7, 0>(p, T, D, st); return; }
+#endif
     }
     launch_mpc_b<H, 0, 0>(p, T, D, st);
 }
