@@ -116,8 +116,8 @@ struct EnvParams {
     uint8_t *flags, *done;
     uint8_t *action_hist;          // [V][n_lanes]
     double *bw_hist;               // [V][n_lanes]
-    double *ep_qoe_terms;          // [4][n_lanes]: rebuffer, startup, avg latency, (unused) of the last finished episode
-    uint8_t *ep_actions;           // [V][n_lanes] actions of the last finished episode (auto_reset)
+    double *ep_qoe_terms;          // [4][n_lanes]: rebuffer, startup, avg latency, bitrate variance of the last finished episode
+    double *var_run;               // [n_lanes] sum of |br[a_i] - br[a_(i+1)]| over the running episode so far (:82), in its order
 };
 
 struct abr_env {
@@ -304,20 +304,10 @@ __device__ inline void write_obs(const Lane &s, const EnvParams &p, int64_t i, f
     obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
 }
 
-// previous_bitrates of the episode that just ended, kept for K4 under auto_reset.  Eight
-// independent loads in flight per trip: a plain load -> store loop pays one memory latency per
-// chunk (48 of them per episode end, measured 0.9 k cycles per decision).
-__device__ inline void copy_episode_actions(const EnvParams &p, int64_t i, int32_t V) {
-    int c = 0;
-    for (; c + 8 <= V; c += 8) {
-        uint8_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = p.action_hist[(int64_t)(c + u) * p.n_lanes + i];
-#pragma unroll
-        for (int u = 0; u < 8; u++) p.ep_actions[(int64_t)(c + u) * p.n_lanes + i] = v[u];
-    }
-    for (; c < V; c++) p.ep_actions[(int64_t)c * p.n_lanes + i] = p.action_hist[(int64_t)c * p.n_lanes + i];
-}
+// The variance term of calculate_qoe (Simulator.py:82-83: sum over the episode of |br[a_i] - br[a_(i+1)]|) is accumulated as the
+// episode goes -- the same terms in the same order as the loop over previous_bitrates, hence the same float64 -- and left in
+// ep_qoe_terms[3] when the episode ends.  (Rounds 1-4 copied the episode's 48 actions aside at every auto-reset for K4 to
+// loop over: six dependent rounds of byte loads and stores per lane, ~10 us per episode end for the whole workgroup.)
 
 // MODE 0: reset (fresh lanes run to their first call site)
 // MODE 1: step  (one externally supplied action per lane)
@@ -339,7 +329,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
     bool need_action = false;     // at a call site, waiting for the block loop to hand it an action
     uint8_t done = 0;
     int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0, prev_action = -1;
-    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, var_run = 0.0;
     int32_t step_idx = 0;
     s.running = false; s.done_dl = true;
 
@@ -369,7 +359,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
             s.tlen = p.trace_len[t]; s.trace = p.traces + p.trace_off[t];
             lane_load(s, p, i);
             n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
-            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i]; var_run = p.var_run[i];
             if (done) active = false;
             need_action = active;        // a live lane sits at a call site
         }
@@ -400,6 +390,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                     if (prev_action >= 0)
                         var = fabs(chunk_bitrate(p, s.chunk_id - 1, s.cur_action) -
                                    chunk_bitrate(p, s.chunk_id - 2, prev_action));
+                    var_run = var_run + var;
                 }
                 // per-step split of calculate_qoe (Simulator.py:83-85)
                 const double r = p.wr * (p.G[s.n_rb] - p.G[n_rb_obs]) +
@@ -414,13 +405,13 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
                     p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                     p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
                     p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, s.sumk, s.n_play);
+                    p.ep_qoe_terms[3 * p.n_lanes + i] = var_run;
                     if (p.auto_reset && ended) {
                         // re-arm: this step's obs is the new episode's first call site
-                        copy_episode_actions(p, i, V);
                         lane_init(s, p, offset0);
                         episode_no++;
                         n_su_obs = 0; n_rb_obs = 0;
-                        last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                        last_bw = 0.0; hist_n = 0.0; hist_s = 0.0; var_run = 0.0;
                         done = 0; fresh = true;
                         emit_obs = !s.running;     // already at a call site only if avail_tick[0] == 0
                     }
@@ -527,7 +518,7 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
     if (touched) {
         lane_store(s, p, i);
         p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
-        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s; p.var_run[i] = var_run;
         p.done[i] = done;
         if (MODE != 0) {
             // lanes that were already finished (or finished early in a fused launch)
@@ -624,7 +615,7 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
     bool active = in_range, touched = in_range;
     uint8_t done = 0;
     int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0, offset0 = 0;
-    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, var_run = 0.0;
     double g_su_obs = 0.0, g_rb_obs = 0.0;    // G[n_su_obs], G[n_rb_obs] carried in registers
 
     if (in_range) {
@@ -654,7 +645,7 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
             s.cur.tlen = p.trace_len[t]; s.cur.trace = p.traces + p.trace_off[t];
             lanej_load(s, p, i);
             n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
-            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+            last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i]; var_run = p.var_run[i];
             g_su_obs = p.G[n_su_obs]; g_rb_obs = p.G[n_rb_obs];
             if (done) active = false;
         }
@@ -697,6 +688,7 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                         hist_n = hist_n + 1.0;
                         if (prev_action >= 0)
                             var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
+                        var_run = var_run + var;
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
                     const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
@@ -714,13 +706,13 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                             !p.lane_speeds ? lane_avg_latency(p, s.sumk, s.n_play)
                             : (p.speed_rows >= 2 ? avg_latency_sched(s.pt, s.sumk, s.pt_sum, s.n_play)
                                                  : avg_latency_from(s.sd, s.pt, s.sumk, s.n_play));
+                        p.ep_qoe_terms[3 * p.n_lanes + i] = var_run;
                         if (p.auto_reset && r.ended) {
                             // re-arm: this step's obs is the new episode's first call site
-                            copy_episode_actions(p, i, V);
                             abrx::lanej_init(s, tb, offset0);
                             episode_no++;
                             n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
-                            last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                            last_bw = 0.0; hist_n = 0.0; hist_s = 0.0; var_run = 0.0;
                             done = 0;
                             if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
                         }
@@ -741,7 +733,7 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
     if (touched) {
         lanej_store(s, p, i);
         p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
-        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+        p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s; p.var_run[i] = var_run;
         p.done[i] = done;
     }
 }
@@ -760,11 +752,15 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
 __global__ void episode_qoe_kernel(EnvParams p, double *__restrict__ qoe_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_lanes) return;
-    const uint8_t *acts = p.auto_reset ? p.ep_actions : p.action_hist;
     double variance = 0.0;
-    for (int c = 0; c < p.video_length - 1; c++) {
-        int a0 = acts[(int64_t)c * p.n_lanes + i], a1 = acts[(int64_t)(c + 1) * p.n_lanes + i];
-        variance += fabs(chunk_bitrate(p, c, a0) - chunk_bitrate(p, c + 1, a1));   // :82
+    if (p.auto_reset) {
+        // previous_bitrates now holds the NEXT episode's actions: the finished episode's sum was left here when it ended
+        variance = p.ep_qoe_terms[3 * p.n_lanes + i];
+    } else {
+        for (int c = 0; c < p.video_length - 1; c++) {
+            int a0 = p.action_hist[(int64_t)c * p.n_lanes + i], a1 = p.action_hist[(int64_t)(c + 1) * p.n_lanes + i];
+            variance += fabs(chunk_bitrate(p, c, a0) - chunk_bitrate(p, c + 1, a1));   // :82
+        }
     }
     qoe_out[i] = p.wr * p.ep_qoe_terms[0 * p.n_lanes + i] + p.wv * variance +
                  p.ws * p.ep_qoe_terms[1 * p.n_lanes + i] +
@@ -830,7 +826,7 @@ static size_t mpc_scratch_bytes_max(size_t n_lanes) {
 
 struct Layout {
     size_t G, GP, interval_tick, avail_tick;        // table offsets
-    size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms, ep_actions;
+    size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms;
     size_t mpc_action, mpc_scratch;
     size_t total;
     int32_t max_ticks, n_intervals;
@@ -892,14 +888,13 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->GP = o; o = align_up(o + sizeof(double) * ((size_t)mt + 2), A);
     L->interval_tick = o; o = align_up(o + sizeof(int32_t) * ((size_t)L->n_intervals + 8), A);
     L->avail_tick = o; o = align_up(o + sizeof(int32_t) * (V + 2), A);
-    L->f64_state = o; o = align_up(o + sizeof(double) * 7 * N, A);
+    L->f64_state = o; o = align_up(o + sizeof(double) * 8 * N, A);
     L->i64_state = o; o = align_up(o + sizeof(long long) * 1 * N, A);
     L->i32_state = o; o = align_up(o + sizeof(int32_t) * 15 * N, A);
     L->u8_state = o; o = align_up(o + 2 * N, A);
     L->action_hist = o; o = align_up(o + V * N, A);
     L->bw_hist = o; o = align_up(o + sizeof(double) * V * N, A);
     L->ep_terms = o; o = align_up(o + sizeof(double) * 4 * N, A);
-    L->ep_actions = o; o = align_up(o + V * N, A);
     L->mpc_action = o; o = align_up(o + sizeof(int32_t) * N, A);
     L->mpc_scratch = o; o = align_up(o + mpc_scratch_bytes_max(N), A);
     L->total = o;
@@ -968,7 +963,7 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     const size_t N = (size_t)n_lanes;
     double *f = (double *)(w + L.f64_state);
     p.buf = f; p.last_bw = f + N; p.hist_n = f + 2 * N; p.hist_s = f + 3 * N;
-    p.sd_lane = f + 4 * N; p.pt_lane = f + 5 * N; p.pt_sum = f + 6 * N; p.lane_speeds = nullptr;
+    p.sd_lane = f + 4 * N; p.pt_lane = f + 5 * N; p.pt_sum = f + 6 * N; p.var_run = f + 7 * N; p.lane_speeds = nullptr;
     p.speed_rows = 1;
     p.sumk = (long long *)(w + L.i64_state);
     int32_t *q = (int32_t *)(w + L.i32_state);
@@ -981,7 +976,6 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     p.action_hist = (uint8_t *)(w + L.action_hist);
     p.bw_hist = (double *)(w + L.bw_hist);
     p.ep_qoe_terms = (double *)(w + L.ep_terms);
-    p.ep_actions = (uint8_t *)(w + L.ep_actions);
     e->mpc_action = (int32_t *)(w + L.mpc_action);
     e->mpc_scratch = (void *)(w + L.mpc_scratch);
 

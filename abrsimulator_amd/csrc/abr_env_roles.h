@@ -445,6 +445,7 @@ __device__ __forceinline__ void role_p3_end(const PVars &v, const EnvParams &p) 
 // =====================================================================================================================
 struct SVars {
     double last_bw, hist_n, hist_s, g_su_obs, g_rb_obs;
+    double var_run;                                         // the running episode's sum of |br[a_i] - br[a_(i+1)]| (:82)
     double o_buf, o_pt;                                     // what an observation of this lane shows right now ...
     int32_t o_chunk, o_last, o_k, o_nplay, o_nrb, o_nsu;    // ...
     int32_t n_su_obs, n_rb_obs, episode_no, s_next;
@@ -461,7 +462,7 @@ __device__ __forceinline__ void s_park(uint32_t (*area)[64], const SVars &v) {
     pw_i32(k, v.o_nsu); pw_i32(k, v.n_su_obs); pw_i32(k, v.n_rb_obs); pw_i32(k, v.episode_no); pw_i32(k, v.s_next);
     pw_i32(k, v.a_next); pw_i32(k, v.a_chunk); pw_i32(k, v.a_ep); pw_i32(k, v.last_cb);
     pw_i32(k, (int32_t)v.done | (v.was_done ? 0x100 : 0));
-    pw_i32(k, 0); pw_i32(k, 0); pw_i32(k, 0);
+    pw_f64(k, v.var_run); pw_i32(k, 0);
     park_store<8>(area, k);
 }
 __device__ __forceinline__ void s_unpark(uint32_t (*area)[64], SVars &v) {
@@ -475,6 +476,7 @@ __device__ __forceinline__ void s_unpark(uint32_t (*area)[64], SVars &v) {
     v.a_ep = pr_i32(k, at); v.last_cb = pr_i32(k, at);
     const int32_t fl = pr_i32(k, at);
     v.done = (uint8_t)(fl & 0xff); v.was_done = (fl & 0x100) != 0;
+    v.var_run = pr_f64(k, at);
 }
 
 __device__ __forceinline__ void service_write_obs(const SVars &v, const EnvParams &p, int64_t i, float *obs) {
@@ -525,6 +527,7 @@ __device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 
         v.hist_n = v.hist_n + 1.0;
         if (prev_action >= 0)
             var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
+        v.var_run = v.var_run + var;
         v.o_last = a; v.o_chunk = chunk + 1;
     }
     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
@@ -539,11 +542,11 @@ __device__ __forceinline__ void service_record(SVars &v, const EnvParams &p, M2 
         p.ep_qoe_terms[0 * p.n_lanes + i] = g_rb;
         p.ep_qoe_terms[1 * p.n_lanes + i] = g_su;
         p.ep_qoe_terms[2 * p.n_lanes + i] = m2.lat[sl][l];
+        p.ep_qoe_terms[3 * p.n_lanes + i] = v.var_run;
         if (m2m & kS3Reset) {
-            copy_episode_actions(p, i, p.video_length);
             v.episode_no++;
             v.n_su_obs = 0; v.n_rb_obs = 0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0;
-            v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0;
+            v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.var_run = 0.0;
             v.done = (m2m & kS3Timeout2) ? ABR_DONE_TIMEOUT : 0;
             v.o_chunk = 0; v.o_last = -1;
         }
@@ -558,7 +561,7 @@ __device__ __forceinline__ void role_s_begin(SVars &v, const EnvParams &, ActRin
     const EnvParams &p = fresh_params();
     const int l = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 64 + l;
-    v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0; v.o_buf = 0.0; v.o_pt = 0.0;
+    v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0; v.o_buf = 0.0; v.o_pt = 0.0; v.var_run = 0.0;
     v.o_chunk = 0; v.o_k = 0; v.o_nplay = 0; v.o_nrb = 0; v.o_nsu = 0; v.n_su_obs = 0; v.n_rb_obs = 0;
     v.episode_no = 0; v.s_next = 0; v.last_cb = 0; v.done = 0;
     v.o_last = -1; v.was_done = true;
@@ -566,7 +569,7 @@ __device__ __forceinline__ void role_s_begin(SVars &v, const EnvParams &, ActRin
         v.done = p.done[i];
         v.was_done = v.done != 0;
         v.n_su_obs = p.n_su_obs[i]; v.n_rb_obs = p.n_rb_obs[i]; v.episode_no = p.episode_no[i];
-        v.last_bw = p.last_bw[i]; v.hist_n = p.hist_n[i]; v.hist_s = p.hist_s[i];
+        v.last_bw = p.last_bw[i]; v.hist_n = p.hist_n[i]; v.hist_s = p.hist_s[i]; v.var_run = p.var_run[i];
         v.g_su_obs = p.G[v.n_su_obs]; v.g_rb_obs = p.G[v.n_rb_obs];
         v.o_chunk = p.chunk_id[i]; v.o_last = p.last_action[i]; v.o_k = p.k[i]; v.o_nplay = p.n_play[i];
         v.o_nrb = p.n_rb[i]; v.o_nsu = p.n_su[i]; v.o_buf = p.buf[i];
@@ -629,7 +632,7 @@ __device__ __forceinline__ void role_s_end(SVars &v, const EnvParams &, SplitMai
     service_record(v, p, m2, v.last_cb, obs_out, reward_out, done_out);       // P's last records
     if (!v.was_done) {
         p.n_su_obs[i] = v.n_su_obs; p.n_rb_obs[i] = v.n_rb_obs; p.episode_no[i] = v.episode_no;
-        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s;
+        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s; p.var_run[i] = v.var_run;
         p.done[i] = v.done;
     }
     // lanes that were already finished (or finished early) report their terminal record for the remaining steps
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 // =====================================================================================================================
 struct P2Vars {
     PVars pv;
-    double last_bw, hist_n, hist_s, g_su_obs, g_rb_obs;
+    double last_bw, hist_n, hist_s, g_su_obs, g_rb_obs, var_run;
     int32_t n_su_obs, n_rb_obs;
     uint8_t done;
 };
@@ -705,7 +708,7 @@ __device__ __forceinline__ void p2_park(uint32_t (*area)[64], const P2Vars &v) {
     p_words(k, v.pv);
     pw_f64(k, v.last_bw); pw_f64(k, v.hist_n); pw_f64(k, v.hist_s); pw_f64(k, v.g_su_obs); pw_f64(k, v.g_rb_obs);
     pw_i32(k, v.n_su_obs); pw_i32(k, v.n_rb_obs); pw_i32(k, v.done);
-    pw_i32(k, 0); pw_i32(k, 0); pw_i32(k, 0);
+    pw_f64(k, v.var_run); pw_i32(k, 0);
     park_store<10>(area, k);
 }
 __device__ __forceinline__ void p2_unpark(uint32_t (*area)[64], P2Vars &v, const EnvParams &p) {
@@ -715,20 +718,21 @@ __device__ __forceinline__ void p2_unpark(uint32_t (*area)[64], P2Vars &v, const
     v.last_bw = pr_f64(k, at); v.hist_n = pr_f64(k, at); v.hist_s = pr_f64(k, at); v.g_su_obs = pr_f64(k, at);
     v.g_rb_obs = pr_f64(k, at);
     v.n_su_obs = pr_i32(k, at); v.n_rb_obs = pr_i32(k, at); v.done = (uint8_t)pr_i32(k, at);
+    v.var_run = pr_f64(k, at);
 }
 
 __device__ __forceinline__ void role_p2_begin(P2Vars &v, const EnvParams &) {
     const EnvParams &p = fresh_params();
     const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     player_clear(v.pv, p);
-    v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0;
+    v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0; v.var_run = 0.0;
     v.n_su_obs = 0; v.n_rb_obs = 0; v.done = 0;
     if (i < p.n_lanes) {
         v.done = p.done[i];
         v.pv.was_done = v.done != 0;
         lanej_load(v.pv.s, p, i);
         v.n_su_obs = p.n_su_obs[i]; v.n_rb_obs = p.n_rb_obs[i]; v.pv.episode_no = p.episode_no[i];
-        v.last_bw = p.last_bw[i]; v.hist_n = p.hist_n[i]; v.hist_s = p.hist_s[i];
+        v.last_bw = p.last_bw[i]; v.hist_n = p.hist_n[i]; v.hist_s = p.hist_s[i]; v.var_run = p.var_run[i];
         v.g_su_obs = p.G[v.n_su_obs]; v.g_rb_obs = p.G[v.n_rb_obs];
         v.pv.b_alive = !v.done;
     }
@@ -777,6 +781,7 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                     v.hist_n = v.hist_n + 1.0;
                     if (prev_action >= 0)
                         var = fabs(chunk_bitrate(p, chunk, a) - chunk_bitrate(p, chunk - 1, prev_action));
+                    v.var_run = v.var_run + var;
                 }
                 // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
                 const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
@@ -792,13 +797,13 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                     p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
                     p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
                     p.ep_qoe_terms[2 * p.n_lanes + i] = player_latency(p, s);
+                    p.ep_qoe_terms[3 * p.n_lanes + i] = v.var_run;
                     if (p.auto_reset && sr.ended) {
                         // re-arm: this step's obs is the new episode's first call site
-                        copy_episode_actions(p, i, p.video_length);
                         abrx::lanej_init_player(s, tb);
                         v.pv.episode_no++;
                         v.n_su_obs = 0; v.n_rb_obs = 0; v.g_su_obs = 0.0; v.g_rb_obs = 0.0;
-                        v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0;
+                        v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.var_run = 0.0;
                         v.done = 0;
                         if (!abrx::lanej_wait_call(s, tb)) v.done |= ABR_DONE_TIMEOUT;
                     }
@@ -826,7 +831,7 @@ __device__ __forceinline__ void role_p2_end(const P2Vars &v, const EnvParams &, 
     if (!v.pv.was_done) {
         lanej_store_player(v.pv.s, p, i);
         p.n_su_obs[i] = v.n_su_obs; p.n_rb_obs[i] = v.n_rb_obs; p.episode_no[i] = v.pv.episode_no;
-        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s;
+        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s; p.var_run[i] = v.var_run;
         p.done[i] = v.done;
     }
     // lanes that were already finished (or finished early) report their terminal record for the remaining steps

@@ -54,8 +54,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
 # per-lane state bytes one launch reads and writes back (csrc/abr_env.hip: lane_load/lane_store
-# + the scalars around them): 4 f64 + 1 i64 + 13 i32 + 2 u8
-STATE_BYTES = 4 * 8 + 8 + 13 * 4 + 2
+# + the scalars around them): 5 f64 (incl. the running episode's bitrate-variance sum, round 5) + 1 i64 + 13 i32 + 2 u8
+STATE_BYTES = 5 * 8 + 8 + 13 * 4 + 2
 
 
 def synth_traces(mixed=False):
@@ -562,7 +562,7 @@ def main():
                          "`binding` names the resource that actually limits it")
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["frac_formula"] = ("fused-launch bytes: per decision 32 obs + 4 reward + 1 done + 9 history + 4.07 trace points x 12 "
-                                "= 94.8 B, plus 2 x 94 B of lane state ONCE per launch")
+                                "= 94.8 B, plus 2 x 102 B of lane state ONCE per launch")
         # SURVEY.md 8(d) literally: state read + write (2 x 96) + action in 4 + obs/reward/done out 29 + 4 B per trace point
         # walked, charged PER STEP -- what a one-decision-per-launch kernel moves; a fused launch does not re-read the state
         survey_bytes = N * f_per_launch * (192 + 4 + 29 + 4 * 4.07)

@@ -508,7 +508,7 @@ __device__ __forceinline__ void async_role_service(
     const int32_t V = p.video_length;
     uint8_t done = 0;
     int32_t n_su_obs = 0, n_rb_obs = 0, episode_no = 0;
-    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, g_su_obs = 0.0, g_rb_obs = 0.0;
+    double last_bw = 0.0, hist_n = 0.0, hist_s = 0.0, g_su_obs = 0.0, g_rb_obs = 0.0, var_run = 0.0;
     AST_DECL
     // what an observation of this lane shows right now
     int32_t o_chunk = 0, o_last = -1, o_k = 0, o_nplay = 0, o_nrb = 0, o_nsu = 0;
@@ -519,7 +519,7 @@ __device__ __forceinline__ void async_role_service(
         was_alive = done == 0;
         alive = was_alive;
         n_su_obs = p.n_su_obs[i]; n_rb_obs = p.n_rb_obs[i]; episode_no = p.episode_no[i];
-        last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i];
+        last_bw = p.last_bw[i]; hist_n = p.hist_n[i]; hist_s = p.hist_s[i]; var_run = p.var_run[i];
         g_su_obs = p.G[n_su_obs]; g_rb_obs = p.G[n_rb_obs];
         o_chunk = p.chunk_id[i]; o_last = p.last_action[i]; o_k = p.k[i]; o_nplay = p.n_play[i];
         o_nrb = p.n_rb[i]; o_nsu = p.n_su[i]; o_buf = p.buf[i];
@@ -601,6 +601,7 @@ __device__ __forceinline__ void async_role_service(
                     hist_n = hist_n + 1.0;
                     if (prev_action >= 0)
                         var = fabs(async_bitrate(p, sh, chunk, a) - async_bitrate(p, sh, chunk - 1, prev_action));
+                    var_run = var_run + var;
                     o_last = a; o_chunk = chunk + 1;
                 }
                 // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
@@ -616,11 +617,11 @@ __device__ __forceinline__ void async_role_service(
                     p.ep_qoe_terms[0 * p.n_lanes + i] = g_rb;
                     p.ep_qoe_terms[1 * p.n_lanes + i] = g_su;
                     p.ep_qoe_terms[2 * p.n_lanes + i] = lane_avg_latency(p, sumk, nplay_r);
+                    p.ep_qoe_terms[3 * p.n_lanes + i] = var_run;
                     if (m2 & kM2Reset) {
-                        copy_episode_actions(p, i, V);
                         episode_no++;
                         n_su_obs = 0; n_rb_obs = 0; g_su_obs = 0.0; g_rb_obs = 0.0;
-                        last_bw = 0.0; hist_n = 0.0; hist_s = 0.0;
+                        last_bw = 0.0; hist_n = 0.0; hist_s = 0.0; var_run = 0.0;
                         done = (m2 & kM2Timeout2) ? ABR_DONE_TIMEOUT : 0;
                         o_chunk = 0; o_last = -1;
                     }
@@ -637,7 +638,7 @@ __device__ __forceinline__ void async_role_service(
     if (in_range) {
         if (was_alive) {
             p.n_su_obs[i] = n_su_obs; p.n_rb_obs[i] = n_rb_obs; p.episode_no[i] = episode_no;
-            p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s;
+            p.last_bw[i] = last_bw; p.hist_n[i] = hist_n; p.hist_s[i] = hist_s; p.var_run[i] = var_run;
             p.done[i] = done;
         }
         // lanes that were already finished (or finished early) report their terminal record

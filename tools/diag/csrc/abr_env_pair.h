@@ -144,7 +144,7 @@ __device__ __forceinline__ void pair_s_loop(const EnvParams &p, RingPS &m2, Pair
     if (aborted && !v.done && v.s_next < n_total) v.done |= ABR_DONE_INTERNAL;
     if (!v.was_done) {
         p.n_su_obs[i] = v.n_su_obs; p.n_rb_obs[i] = v.n_rb_obs; p.episode_no[i] = v.episode_no;
-        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s;
+        p.last_bw[i] = v.last_bw; p.hist_n[i] = v.hist_n; p.hist_s[i] = v.hist_s; p.var_run[i] = v.var_run;
         p.done[i] = v.done;
     }
     for (int32_t t2 = v.s_next; t2 < n_total; t2++) {      // lanes that finished early report their terminal record again
