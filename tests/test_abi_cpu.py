@@ -91,7 +91,7 @@ def test_workspace_bytes_and_validation(L):
     lib = L.lib()
     n = C.c_size_t()
     assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 65536, C.byref(n)) == 0
-    per_lane = 7 * 8 + 8 + 15 * 4 + 2 + 48 + 48 * 8 + 4 * 8 + 48 + 4 + 72   # incl. per-lane speed state, MPC action + predictor scratch
+    per_lane = 8 * 8 + 8 + 15 * 4 + 2 + 48 + 48 * 8 + 4 * 8 + 4 + 72   # incl. per-lane speed state, the running variance sum, MPC action + predictor scratch
     assert n.value >= 65536 * per_lane and n.value < 65536 * per_lane + 32 * 2 ** 20
     n2 = C.c_size_t()
     assert lib.abr_env_workspace_bytes(C.byref(_cfg(L)), 131072, C.byref(n2)) == 0
