@@ -167,3 +167,51 @@ print("intervals the cursor is behind at a call site (share of call sites):",
       "  ".join(f"{i}{'+' if i == 8 else ''}: {100.0 * c / advs.size:.1f} %" for i, c in enumerate(h)))
 wmax = advs.reshape(W, 64, V).max(1)
 print("  ... maximum over the 64 lanes of a wave:", "  ".join(f"{i}{'+' if i == 8 else ''}: {100.0 * c / wmax.size:.1f} %" for i, c in enumerate(np.bincount(np.minimum(wmax.ravel(), 8), minlength=9))))
+
+
+def lane_async(theta, trip, rest, cap=10 ** 9):
+    """one thread per lane, NO step lockstep inside the wave: a lane that finishes its download waits until `theta` lanes of its wave
+    wait (or none can run), then the wave runs the rest of the step (player, service, next begin: `rest` instructions, masked to the
+    waiting lanes) once; otherwise it runs one download trip (`trip` instructions) for the lanes that have one.  `cap`: a lane may
+    not finish a decision more than `cap` decisions ahead of the slowest lane of its wave.  Returns vector instructions per
+    wave-decision, the spread of step indices inside a wave when the first lane ends its episode, and the number of pieces an
+    output row of the wave (64 lanes of one decision) is written in."""
+    tot = 0
+    spread = []
+    pieces = 0
+    for w in range(W):
+        T = g[w]                                 # [64, V]
+        s = np.zeros(64, np.int64)
+        r = T[:, 0].astype(np.int64).copy()
+        cost = 0
+        seen = False
+        while True:
+            live = s < V
+            if not live.any():
+                break
+            act = live & (r > 0)
+            fin = live & (r == 0)
+            wait = fin & (s - s[live].min() < cap)
+            if not act.any() or wait.sum() >= theta:
+                cost += rest
+                pieces += len(np.unique(s[wait]))
+                s[wait] += 1
+                nxt = wait & (s < V)
+                r[nxt] = T[nxt, s[nxt]]
+                if not seen and (s >= V).any():
+                    seen = True
+                    spread.append(int(s.max() - s.min()))
+            else:
+                cost += trip
+                r[act] -= 1
+        tot += cost
+    return tot / (W * V), float(np.mean(spread)), pieces / (W * V)
+
+
+print("one thread per lane without step lockstep in the wave (instructions per wave-decision; trip 129, rest of the step 338):")
+base_j = g.max(1).mean() * 129 + 338
+print(f"  shipped (every lane of the wave at the same decision)      {base_j:6.0f}")
+for th, cap in ((16, 99), (32, 99), (40, 99), (48, 99), (56, 99), (32, 2), (40, 2), (48, 2), (32, 4), (40, 4), (48, 4), (40, 8), (32, 1), (48, 1)):
+    c, sp, pc = lane_async(th, 129, 338, cap)
+    print(f"  rest of the step once {th:2d} lanes wait, at most {cap:2d} decisions ahead   {c:6.0f}   ({base_j / c:.2f}x; decisions apart inside a wave "
+          f"at the first episode end: {sp:.1f}; an output row is written in {pc:.1f} pieces)")
