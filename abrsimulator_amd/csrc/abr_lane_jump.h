@@ -129,6 +129,11 @@ ABR_HD void lanej_play(LaneJ &s, const Tables &t, int32_t a) {
 // reference's own sequence.  The switch point affects speed only, never a result; measured
 // on one MI355X box at 65 536 lanes (profiles/r02_ab_drain_tail.txt): 8-32 ticks are
 // equivalent (7.3-7.4e9 env-steps/s), 64 costs 5 %, 128 costs 20 %.
+// (A buffer that runs dry is the player wave's slowest case -- six segments and the whole tail, one lane in 25, so 86 % of a
+// wave's decisions have one -- and only the tick it ends at is needed, not its values; but that tick cannot be had from
+// real arithmetic: buffer levels are sums of chunk lengths and tick-sized subtractions, so b / sd sits within rounding of
+// a whole number exactly when it matters, and which side of zero the k-th result falls on is decided by the roundings
+// themselves.  Built and measured in round 5, profiles/r05_experiments_not_kept.txt.)
 constexpr int kDrainTail = ABR_K_DRAIN_TAIL;
 ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     ChainState cs;
@@ -138,10 +143,18 @@ ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     bool below = false;
     while (a < m && !below) a += chain_segment<STOP_LE>(cs, -sd, tail, m - a, below);
     double b = cs.x;
+    ABR_STAMP(24);
+#ifdef ABR_DRAIN_HOOK
+    const int32_t a_seg = a;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
     while (a < m && b > 0.0) { b = b - sd; a++; }
+    ABR_STAMP(25);
+#ifdef ABR_DRAIN_HOOK
+    ABR_DRAIN_HOOK(a > 0 && b <= 0.0, a - a_seg);   // host-side analysis builds: did it run dry, ticks of the plain tail
+#endif
     b_io = b; a_out = a;
     return a > 0 && b <= 0.0;
 }
@@ -198,6 +211,7 @@ ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
     // buffer_level < start_up_length once any tick has run) except right after init when
     // start_up_length <= 0: tick 0 itself counts as start-up, every later one does not.
     if (s.su && s.buf >= t.start_up_length) s.su = false;
+    ABR_STAMP(23);
     if (s.su) {
         s.n_su += m;                                   // :137-138; nothing plays, buffer untouched
     } else if (s.be) {

@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
-V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, float(os.environ.get("ABR_BENCH_MAX_BUFFER", "20.0")), 8.0, 1.0   # (the override is a diagnostic: 1e9 = buffer_full never gates a download)
+V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, float(os.environ.get("ABR_BENCH_MAX_BUFFER", "20.0")), 8.0, float(os.environ.get("ABR_BENCH_INTERVAL", "1.0"))   # (the overrides are diagnostics: max_buffer 1e9 = buffer_full never gates a download; a longer trace interval = fewer constant changes per download)
 WEIGHTS = [4.3, 1.0, 1.0, 0.1]
 N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000   # (the override is a cache-residency diagnostic)
 STRONG_TOTAL = int(os.environ.get("ABR_BENCH_STRONG_TOTAL", "1048576"))   # configs[3] / north_star: the scaling

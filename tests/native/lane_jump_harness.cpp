@@ -19,6 +19,24 @@ static long long g_pred[5];
 
 extern "C" {
 
+// drain_to_zero against the reference's own loop (buffer_level -= speed*dt until <= 0, Simulator.py:184,:194), n cases:
+// returns the index of the first case that differs (ticks taken, ran-dry flag, the value), or -1; stats[0] = cases that ran dry
+int64_t lj_drain_check(const double *b0, const double *sd, const int32_t *m, int64_t n, long long *stats) {
+    stats[0] = 0;
+    for (int64_t c = 0; c < n; c++) {
+        double b = b0[c];
+        int32_t a = 0;
+        while (a < m[c] && b > 0.0) { b = b - sd[c]; a++; }                 // the naive loop
+        const bool zero = a > 0 && b <= 0.0;
+        double bj = b0[c];
+        int32_t aj = 0;
+        const bool zj = abrx::drain_to_zero(bj, sd[c], m[c], aj);
+        if (zj != zero || aj != a || bj != b) return c;
+        stats[0] += zero ? 1 : 0;
+    }
+    return -1;
+}
+
 void lj_predict_stats(long long *out, int reset) {
     for (int i = 0; i < 5; i++) { out[i] = g_pred[i]; if (reset) g_pred[i] = 0; }
 }

@@ -244,3 +244,46 @@ def test_call_site_prediction_of_the_download_side(H, oracle):
     assert wrong == 0
     # made > gated: buffer_full at the completing tick that the wait for availability clears again; uncovered: gated out of start-up
     assert gated > 2000 and made >= covered > 0.9 * gated, list(stats)
+
+
+def test_drain_to_zero_against_the_plain_loop(H):
+    """drain_to_zero (exact jumps far from zero, plain subtractions near it) against `buffer_level -= speed * dt` tick by
+    tick (Simulator.py:184, :194): the same number of ticks, the same ran-dry answer, the same float64 value.  Half of the
+    cases start where the workload's buffers really are: within a few ulps of k * sd, and on values the rounded sequence
+    itself visits on its way to zero -- there the tick at which the result is first <= 0 is decided by the roundings."""
+    rng = np.random.default_rng(77)
+    n = 400_000
+    sd = np.where(rng.random(n) < 0.5, 0.01, rng.uniform(0.003, 0.03, n))
+    b0 = rng.uniform(0.0, 1.0, n) ** 2 * 40.0
+    m = rng.integers(0, 2500, n).astype(np.int32)
+    # adversarial: multiples of sd, nudged by -3..3 ulps
+    k = rng.integers(1, 2400, n)
+    adv = k * sd
+    adv = np.nextafter(adv, np.where(rng.random(n) < 0.5, np.inf, -np.inf))
+    for _ in range(2):
+        adv = np.where(rng.random(n) < 0.5, np.nextafter(adv, np.inf), adv)
+    # ... and values of the sequence run BACKWARDS from a tiny remainder: b0 = r + sd + sd + ... (k times, rounded each time),
+    # so that the forward sequence lands within rounding of r, on either side of zero
+    r = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-17, -9, n)
+    back = r.copy()
+    kk = rng.integers(1, 600, n)
+    for j in range(600):
+        back = np.where(j < kk, back + sd, back)
+    B0 = np.concatenate([b0, adv, back, adv, back])
+    SD = np.concatenate([sd] * 5)
+    M = np.concatenate([m, (k + rng.integers(-2, 3, n)).astype(np.int32), (kk + rng.integers(-2, 3, n)).astype(np.int32),
+                        np.full(n, 5000, np.int32), np.full(n, 5000, np.int32)]).astype(np.int32)
+    M = np.maximum(M, 0).astype(np.int32)
+    H.lj_drain_check.restype = C.c_int64
+
+    def check(b_, sd_, m_):
+        keep = b_ > 0.0                  # the function is only called on a playing lane (buffer_level > 0)
+        b_, sd_, m_ = (np.ascontiguousarray(a[keep]) for a in (b_, sd_, np.maximum(m_, 0).astype(np.int32)))
+        stats = (C.c_longlong * 2)()
+        bad = H.lj_drain_check(b_.ctypes.data_as(C.POINTER(C.c_double)), sd_.ctypes.data_as(C.POINTER(C.c_double)),
+                               m_.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(len(b_)), stats)
+        assert bad == -1, (bad, b_[bad], sd_[bad], m_[bad])
+        return stats[0]
+
+    assert check(b0, sd, m) > 50_000                     # random starts
+    assert check(B0[n:], SD[n:], M[n:]) > 500_000         # near-multiples of sd and the sequence's own values

@@ -13,6 +13,9 @@ static thread_local char g_end[256];
 static thread_local int g_nend;
 #define ABR_SEGMENT_END_HOOK(STOP, a, n, hit, inside) \
     do { if ((STOP) == 0 && g_nend < 255) g_end[g_nend++] = ((a) == (n) && !(hit) && (inside)) ? 'B' : 'X'; } while (0)
+// the player's drains of a step: segments of those that ran dry / did not, ticks of the plain tail
+static thread_local int g_dry, g_tail_ticks;
+#define ABR_DRAIN_HOOK(dry, tail) do { g_dry |= (dry) ? 1 : 0; g_tail_ticks += (tail); } while (0)
 #include "abr_lane_jump.h"
 #include "abr_tick_tables.h"
 
@@ -70,4 +73,33 @@ extern "C" int seg_episode(double interval, double L, int32_t V, double max_buff
 
 extern "C" void seg_gated(int32_t *out, int32_t V) {
     for (int i = 0; i < V && i < 4096; i++) out[i] = g_gated[i];
+}
+
+// the player side of each decision of an episode: drain segments, whether a drain ran the buffer dry, ticks of the plain tail
+extern "C" int seg_episode_player(double interval, double L, int32_t V, double max_buffer, double start_up, int32_t max_ticks,
+                                  const double *ladder, const double *trace, int32_t tlen, int32_t offset,
+                                  const int32_t *actions, int32_t *le_out, int32_t *dry_out, int32_t *tail_out) {
+    static thread_local abrx::TickTables tt;
+    static thread_local bool have = false;
+    if (!have) {
+        tt = abrx::build_tick_tables(interval, L, 1.0, V, max_ticks, (int32_t)(max_ticks * 0.01 / interval + 4.0));
+        have = true;
+    }
+    abrx::Tables t;
+    t.G = tt.G.data(); t.interval_tick = tt.interval_tick.data(); t.avail_tick = tt.avail_tick.data();
+    t.L = L; t.sd = tt.sd; t.max_buffer = max_buffer; t.start_up_length = start_up; t.V = V;
+    t.max_ticks = max_ticks; t.per_lane_speed = false; t.speed_rows = 0; t.speed_stride = 0; t.speeds = nullptr;
+    abrx::LaneJ s;
+    s.cur.trace = trace; s.cur.tlen = tlen; s.sd = t.sd;
+    abrx::lanej_init(s, t, offset);
+    if (!abrx::lanej_wait_call(s, t)) return -2;
+    for (int step = 0; step < V; step++) {
+        const abrx::StepStart st = abrx::lanej_begin_step(s.cur, t, s.k, s.chunk_id);
+        const abrx::Download dd = abrx::lanej_download(s.cur, t, st, s.k, ladder[actions[step]] * L);
+        g_seg[1] = g_seg[2] = 0; g_dry = 0; g_tail_ticks = 0;
+        abrx::StepResult sr = abrx::lanej_after_download(s, t, dd, st.avail_next, actions[step]);
+        if (sr.timeout) return -2;
+        le_out[step] = g_seg[1] + g_seg[2]; dry_out[step] = g_dry; tail_out[step] = g_tail_ticks;
+    }
+    return 0;
 }
