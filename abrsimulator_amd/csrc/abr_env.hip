@@ -575,18 +575,43 @@ __device__ inline void lanej_store(const LaneJ &s, const EnvParams &p, int64_t i
     if (p.lane_speeds && p.speed_rows >= 2) { p.pl_left[i] = s.pl_left; p.play_id[i] = s.play_id; p.pt_sum[i] = s.pt_sum; }
 }
 
+// Outputs (observations, rewards, done bytes, the actions and history rows) are written once and never read by the launch that
+// writes them: non-temporal stores, so that they do not evict the tick tables, traces and lane state from the XCD's L2.  Same-box
+// A/B (profiles/r05_ab_nt_stores.txt): +1.0 % at 65 536 lanes (three-wave kernel's service role), +0.6 % at 131 072 (two-wave
+// kernel's player), +2.7 % at 1 048 576 (one thread per lane: 1.9 GB of outputs per launch).  -DABR_NO_NT_STORES builds the plain form.
+#ifndef ABR_NO_NT_STORES
+#define ABR_OUT(ref, val) __builtin_nontemporal_store((val), &(ref))
+#else
+#define ABR_OUT(ref, val) ((ref) = (val))
+#endif
+
 __device__ inline void write_obs_j(const LaneJ &s, const EnvParams &p, int64_t i, float *obs,
                                    double last_bw) {
     if (!obs) return;
     const int64_t n = p.n_lanes;
-    obs[ABR_OBS_CHUNK_ID * n + i] = (float)s.chunk_id;
-    obs[ABR_OBS_LAST_BITRATE * n + i] = (float)s.last_action;
-    obs[ABR_OBS_LAST_BANDWIDTH * n + i] = (float)last_bw;
-    obs[ABR_OBS_BUFFER_LEVEL * n + i] = (float)s.buf;
-    obs[ABR_OBS_GLOBAL_TIME * n + i] = (float)p.G[s.k];
-    obs[ABR_OBS_PLAY_TIME * n + i] = (float)(p.lane_speeds ? s.pt : p.GP[s.n_play]);
-    obs[ABR_OBS_REBUFFER_TIME * n + i] = (float)p.G[s.n_rb];
-    obs[ABR_OBS_STARTUP_TIME * n + i] = (float)p.G[s.n_su];
+    ABR_OUT(obs[ABR_OBS_CHUNK_ID * n + i], (float)s.chunk_id);
+    ABR_OUT(obs[ABR_OBS_LAST_BITRATE * n + i], (float)s.last_action);
+    ABR_OUT(obs[ABR_OBS_LAST_BANDWIDTH * n + i], (float)last_bw);
+    ABR_OUT(obs[ABR_OBS_BUFFER_LEVEL * n + i], (float)s.buf);
+    ABR_OUT(obs[ABR_OBS_GLOBAL_TIME * n + i], (float)p.G[s.k]);
+    ABR_OUT(obs[ABR_OBS_PLAY_TIME * n + i], (float)(p.lane_speeds ? s.pt : p.GP[s.n_play]));
+    ABR_OUT(obs[ABR_OBS_REBUFFER_TIME * n + i], (float)p.G[s.n_rb]);
+    ABR_OUT(obs[ABR_OBS_STARTUP_TIME * n + i], (float)p.G[s.n_su]);
+}
+
+// the same rows from table values the caller has already loaded: G[k], play_time, G[n_rb], G[n_su]
+__device__ inline void write_obs_vals(const LaneJ &s, const EnvParams &p, int64_t i, float *obs, double last_bw,
+                                      double g_k, double g_play, double g_rb, double g_su) {
+    if (!obs) return;
+    const int64_t n = p.n_lanes;
+    ABR_OUT(obs[ABR_OBS_CHUNK_ID * n + i], (float)s.chunk_id);
+    ABR_OUT(obs[ABR_OBS_LAST_BITRATE * n + i], (float)s.last_action);
+    ABR_OUT(obs[ABR_OBS_LAST_BANDWIDTH * n + i], (float)last_bw);
+    ABR_OUT(obs[ABR_OBS_BUFFER_LEVEL * n + i], (float)s.buf);
+    ABR_OUT(obs[ABR_OBS_GLOBAL_TIME * n + i], (float)g_k);
+    ABR_OUT(obs[ABR_OBS_PLAY_TIME * n + i], (float)g_play);
+    ABR_OUT(obs[ABR_OBS_REBUFFER_TIME * n + i], (float)g_rb);
+    ABR_OUT(obs[ABR_OBS_STARTUP_TIME * n + i], (float)g_su);
 }
 
 // Waves per SIMD the one-thread-per-lane kernels are compiled for.  Round 2: four (128 VGPRs + 48 B of scratch) instead
@@ -666,11 +691,11 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                 else a = (int32_t)philox_action(seed, (uint64_t)(p.lane_id_base + i),
                                                 (uint32_t)s.chunk_id, (uint32_t)episode_no,
                                                 (uint32_t)p.n_rates);
-                if (MODE == 2 && actions_out) actions_out[o] = a;
+                if (MODE == 2 && actions_out) ABR_OUT(actions_out[o], a);
                 if (a < 0 || a >= p.n_rates) {
                     done |= ABR_DONE_BADACT;
-                    if (reward_out) reward_out[o] = 0.0f;
-                    if (done_out) done_out[o] = done;
+                    if (reward_out) ABR_OUT(reward_out[o], 0.0f);
+                    if (done_out) ABR_OUT(done_out[o], (uint8_t)done);
                     write_obs_j(s, p, i, obs, last_bw);
                     active = false;
                 } else {
@@ -681,8 +706,8 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                     double var = 0.0;
                     if (r.hit) {
                         const int64_t h = (int64_t)chunk * p.n_lanes + i;
-                        p.bw_hist[h] = r.bw;                                   // :164
-                        p.action_hist[h] = (uint8_t)a;                         // :165
+                        ABR_OUT(p.bw_hist[h], r.bw);                            // :164
+                        ABR_OUT(p.action_hist[h], (uint8_t)a);                  // :165
                         last_bw = r.bw;
                         hist_s = hist_s + 1.0 / r.bw;   // sum(1/x), list order (mpc.py:86-88)
                         hist_n = hist_n + 1.0;
@@ -695,8 +720,8 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                     const double rew = p.wr * (g_rb - g_rb_obs) + p.ws * (g_su - g_su_obs) + p.wv * var;
                     if (r.ended) done |= ABR_DONE_EPISODE;
                     if (r.timeout) done |= ABR_DONE_TIMEOUT;
-                    if (reward_out) reward_out[o] = (float)rew;
-                    if (done_out) done_out[o] = done;
+                    if (reward_out) ABR_OUT(reward_out[o], (float)rew);
+                    if (done_out) ABR_OUT(done_out[o], (uint8_t)done);
                     n_su_obs = s.n_su; n_rb_obs = s.n_rb;
                     g_su_obs = g_su; g_rb_obs = g_rb;
                     if (r.ended || r.timeout) {
@@ -722,9 +747,9 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                 }
             } else if (in_range) {
                 // lanes already finished report their terminal record again
-                if (reward_out) reward_out[o] = 0.0f;
-                if (done_out) done_out[o] = done;
-                if (MODE == 2 && actions_out) actions_out[o] = -1;
+                if (reward_out) ABR_OUT(reward_out[o], 0.0f);
+                if (done_out) ABR_OUT(done_out[o], (uint8_t)done);
+                if (MODE == 2 && actions_out) ABR_OUT(actions_out[o], (int32_t)-1);
                 write_obs_j(s, p, i, obs, last_bw);
             }
         }

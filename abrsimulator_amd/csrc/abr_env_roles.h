@@ -29,14 +29,7 @@
 #ifndef ABR_ENV_ROLES_H
 #define ABR_ENV_ROLES_H
 
-// Outputs (observations, rewards, done bytes, the history rows) are written once and never read by the launch that writes
-// them: non-temporal stores, so that they do not evict the tick tables and traces from the XCD's L2 (+1.0 % at fuse 48,
-// +0.5 % at fuse 20, same-box A/B: profiles/r05_ab_nt_stores.txt; -DABR_NO_NT_STORES builds the plain form).
-#ifndef ABR_NO_NT_STORES
-#define ABR_OUT(ref, val) __builtin_nontemporal_store((val), &(ref))
-#else
-#define ABR_OUT(ref, val) ((ref) = (val))
-#endif
+// (output stores go through ABR_OUT, abr_env.hip: non-temporal)
 
 // issue priorities of the three roles (s_setprio; A/B knobs: profiles/r03_ab_split3.txt, r05_experiments_not_kept.txt (3))
 #ifndef ABR_PRIO_D
@@ -759,8 +752,8 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
             const int32_t a = m.action[pb][l];
             if (fl & kRecBadAct) {
                 v.done |= ABR_DONE_BADACT;
-                if (reward_out) reward_out[o] = 0.0f;
-                if (done_out) done_out[o] = v.done;
+                if (reward_out) ABR_OUT(reward_out[o], 0.0f);
+                if (done_out) ABR_OUT(done_out[o], (uint8_t)v.done);
                 write_obs_j(s, p, i, obs, v.last_bw);
                 v.pv.b_alive = false;
             } else {
@@ -771,11 +764,16 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                 ABR_STAMP(9);
                 const abrx::StepResult sr = abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
                 ABR_STAMP(13);
+                // everything the step reports from the tick tables -- the reward's two clocks and the observation's four -- in
+                // ONE burst of loads, consumed after the divisions below (this wave is the two-wave kernel's critical one: two
+                // rounds of dependent loads were two L2 round trips per iteration)
+                const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
+                double o_k = p.G[s.k], o_pl = p.lane_speeds ? s.pt : p.GP[s.n_play], o_rb = g_rb, o_su = g_su;
                 double var = 0.0;
                 if (sr.hit) {
                     const int64_t h = (int64_t)chunk * p.n_lanes + i;
-                    p.bw_hist[h] = sr.bw;                                  // :164
-                    p.action_hist[h] = (uint8_t)a;                         // :165
+                    ABR_OUT(p.bw_hist[h], sr.bw);                           // :164
+                    ABR_OUT(p.action_hist[h], (uint8_t)a);                  // :165
                     v.last_bw = sr.bw;
                     v.hist_s = v.hist_s + 1.0 / sr.bw;  // sum(1/x), list order (mpc.py:86-88)
                     v.hist_n = v.hist_n + 1.0;
@@ -784,18 +782,17 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                     v.var_run = v.var_run + var;
                 }
                 // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
-                const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
                 const double rew = p.wr * (g_rb - v.g_rb_obs) + p.ws * (g_su - v.g_su_obs) + p.wv * var;
                 if (sr.ended) v.done |= ABR_DONE_EPISODE;
                 if (sr.timeout) v.done |= ABR_DONE_TIMEOUT;
-                if (reward_out) reward_out[o] = (float)rew;
-                if (done_out) done_out[o] = v.done;
+                if (reward_out) ABR_OUT(reward_out[o], (float)rew);
+                if (done_out) ABR_OUT(done_out[o], (uint8_t)v.done);
                 v.n_su_obs = s.n_su; v.n_rb_obs = s.n_rb;
                 v.g_su_obs = g_su; v.g_rb_obs = g_rb;
                 ABR_STAMP(14);
                 if (sr.ended || sr.timeout) {
-                    p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
-                    p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                    p.ep_qoe_terms[0 * p.n_lanes + i] = g_rb;
+                    p.ep_qoe_terms[1 * p.n_lanes + i] = g_su;
                     p.ep_qoe_terms[2 * p.n_lanes + i] = player_latency(p, s);
                     p.ep_qoe_terms[3 * p.n_lanes + i] = v.var_run;
                     if (p.auto_reset && sr.ended) {
@@ -806,10 +803,12 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                         v.last_bw = 0.0; v.hist_n = 0.0; v.hist_s = 0.0; v.var_run = 0.0;
                         v.done = 0;
                         if (!abrx::lanej_wait_call(s, tb)) v.done |= ABR_DONE_TIMEOUT;
+                        o_k = p.G[s.k]; o_pl = p.lane_speeds ? s.pt : p.GP[s.n_play];
+                        o_rb = p.G[s.n_rb]; o_su = p.G[s.n_su];
                     }
                 }
                 ABR_STAMP(15);
-                write_obs_j(s, p, i, obs, v.last_bw);
+                write_obs_vals(s, p, i, obs, v.last_bw, o_k, o_pl, o_rb, o_su);
                 if (v.done) v.pv.b_alive = false;
                 ABR_STAMP(16);
             }
@@ -837,9 +836,9 @@ __device__ __forceinline__ void role_p2_end(const P2Vars &v, const EnvParams &, 
     // lanes that were already finished (or finished early) report their terminal record for the remaining steps
     for (int32_t t2 = v.pv.b_step; t2 < n_total; t2++) {
         const int64_t o = (int64_t)t2 * p.n_lanes + i;
-        if (reward_out) reward_out[o] = 0.0f;
-        if (done_out) done_out[o] = v.done;
-        if (MODE == 2 && actions_out) actions_out[o] = -1;
+        if (reward_out) ABR_OUT(reward_out[o], 0.0f);
+        if (done_out) ABR_OUT(done_out[o], (uint8_t)v.done);
+        if (MODE == 2 && actions_out) ABR_OUT(actions_out[o], (int32_t)-1);
         write_obs_j(v.pv.s, p, i, obs_out ? obs_out + (int64_t)t2 * ABR_OBS_DIM * p.n_lanes : nullptr, v.last_bw);
     }
 }
