@@ -703,6 +703,9 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                     const int32_t chunk = s.chunk_id;
                     const abrx::StepResult r = abrx::lanej_download_and_wait(
                         s, tb, st, chunk_bitrate(p, chunk, a) * p.chunk_length /* :156 */, a);
+                    // the reward's two clocks and the observation's four tick-table values in ONE burst of loads
+                    const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
+                    double o_k = p.G[s.k], o_pl = p.lane_speeds ? s.pt : p.GP[s.n_play], o_rb = g_rb, o_su = g_su;
                     double var = 0.0;
                     if (r.hit) {
                         const int64_t h = (int64_t)chunk * p.n_lanes + i;
@@ -716,7 +719,6 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                         var_run = var_run + var;
                     }
                     // ---- step boundary: per-step split of calculate_qoe (:83-85) ----
-                    const double g_rb = p.G[s.n_rb], g_su = p.G[s.n_su];
                     const double rew = p.wr * (g_rb - g_rb_obs) + p.ws * (g_su - g_su_obs) + p.wv * var;
                     if (r.ended) done |= ABR_DONE_EPISODE;
                     if (r.timeout) done |= ABR_DONE_TIMEOUT;
@@ -725,8 +727,8 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                     n_su_obs = s.n_su; n_rb_obs = s.n_rb;
                     g_su_obs = g_su; g_rb_obs = g_rb;
                     if (r.ended || r.timeout) {
-                        p.ep_qoe_terms[0 * p.n_lanes + i] = p.G[s.n_rb];
-                        p.ep_qoe_terms[1 * p.n_lanes + i] = p.G[s.n_su];
+                        p.ep_qoe_terms[0 * p.n_lanes + i] = g_rb;
+                        p.ep_qoe_terms[1 * p.n_lanes + i] = g_su;
                         p.ep_qoe_terms[2 * p.n_lanes + i] =
                             !p.lane_speeds ? lane_avg_latency(p, s.sumk, s.n_play)
                             : (p.speed_rows >= 2 ? avg_latency_sched(s.pt, s.sumk, s.pt_sum, s.n_play)
@@ -740,9 +742,11 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
                             last_bw = 0.0; hist_n = 0.0; hist_s = 0.0; var_run = 0.0;
                             done = 0;
                             if (!abrx::lanej_wait_call(s, tb)) done |= ABR_DONE_TIMEOUT;
+                            o_k = p.G[s.k]; o_pl = p.lane_speeds ? s.pt : p.GP[s.n_play];
+                            o_rb = p.G[s.n_rb]; o_su = p.G[s.n_su];
                         }
                     }
-                    write_obs_j(s, p, i, obs, last_bw);
+                    write_obs_vals(s, p, i, obs, last_bw, o_k, o_pl, o_rb, o_su);
                     if (done) active = false;
                 }
             } else if (in_range) {
