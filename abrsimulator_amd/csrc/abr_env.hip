@@ -634,7 +634,6 @@ __global__ ABR_JUMP_BOUNDS(MODE) void env_jump_kernel(
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < p.n_lanes;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
-    const int32_t V = p.video_length;
     const abrx::Tables tb = make_tables(p);
     LaneJ s;
     bool active = in_range, touched = in_range;
