@@ -254,12 +254,17 @@ __device__ __forceinline__ void role_d_pre(DVars &v, const EnvParams &p, SplitMa
 __device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, const abrx::Tables &tb, int32_t t) {
     const int l = threadIdx.x & 63;
     const int cb = t & 1;
-    if (!m.fb_alive[cb][l]) v.d_alive = false;
-    else if (v.issued_step != m.fb_step[cb][l] || v.issued_k != m.fb_k[cb][l]) {
+    // everything the common cases look at in ONE round of LDS reads: this wave is on the iteration's critical path, and a read
+    // issued only inside the branch that needs it is a round trip of its own (round 5: this and the same on the player's
+    // side, +3.2 % at fuse 48, +2.2 % at fuse 20: profiles/r05_ab_fixed_costs.txt)
+    const int32_t f_alive = m.fb_alive[cb][l], f_step = m.fb_step[cb][l], f_k = m.fb_k[cb][l], f_pf = m.fb_pf[cb][l];
+    const double f_buf = m.fb_buf[cb][l];
+    if (!f_alive) v.d_alive = false;
+    else if (v.issued_step != f_step || v.issued_k != f_k) {
         // gated by buffer_full: take the player's word for where the download starts and
         // redo it from the cursor it started from
         v.d_alive = true;
-        v.d_step = m.fb_step[cb][l]; v.d_k = m.fb_k[cb][l];
+        v.d_step = f_step; v.d_k = f_k;
         v.d_chunk = m.fb_chunk[cb][l]; v.d_ep = m.fb_episode[cb][l];
         if (v.issued_step == v.d_step) { v.cur.j = v.snap_j; v.cur.tpos = v.snap_tpos; }
         v.issued_step = -1;
@@ -271,8 +276,8 @@ __device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, const ab
         // this iteration is about to start -- begins, instead of speculating "not gated" and repeating it.  (A lane whose
         // buffer sits at max_buffer is gated at almost every decision; round 5: one such lane made its workgroup, and with
         // it the whole launch, 30 % longer.  d_chunk > 0: not across an episode end, whose first call site is never gated.)
-        const int32_t pf = m.fb_pf[cb][l];
-        const double buf = m.fb_buf[cb][l];
+        const int32_t pf = f_pf;
+        const double buf = f_buf;
         if (abrx::lanej_gate_possible(buf, pf & 1, pf & 2, v.issued_ndl, tb)) {
             int32_t kn;
             if (abrx::lanej_predict_next_call(buf, v.issued_k, v.issued_ndl, v.issued_avail, tb, kn)) {
@@ -387,9 +392,14 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
     ABR_STAMP(8);
     if (v.b_alive && v.b_step < n_total && t >= 1) {
         const int32_t fl = m.flags[pb][l];
+        // the whole record in ONE round of LDS reads, not a second one behind the validity test (this wave is as critical as
+        // the download wave)
+        const int32_t r_step = m.step[pb][l], r_k = m.k_start[pb][l], r_a = m.action[pb][l], r_ndl = m.n_dl[pb][l],
+                      r_avail = m.avail_next[pb][l];
+        const double r_dl = m.dl[pb][l];
         // accept the download only if it started at exactly this lane's call-site tick
-        if ((fl & kRecValid) && m.step[pb][l] == v.b_step && m.k_start[pb][l] == s.k) {
-            const int32_t a = m.action[pb][l];
+        if ((fl & kRecValid) && r_step == v.b_step && r_k == s.k) {
+            const int32_t a = r_a;
             meta = kS3Valid | (a & 0xff);
             m2.step[cb2][l] = v.b_step;
             if (fl & kRecBadAct) {
@@ -397,8 +407,8 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
                 v.b_alive = false;
             } else {
                 abrx::Download d;
-                d.dl = m.dl[pb][l]; d.n_dl = m.n_dl[pb][l]; d.hit = (fl & kRecHit) != 0;
-                const abrx::StepResult sr = abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
+                d.dl = r_dl; d.n_dl = r_ndl; d.hit = (fl & kRecHit) != 0;
+                const abrx::StepResult sr = abrx::lanej_after_download(s, tb, d, r_avail, a);
                 if (sr.hit) meta |= kS3Hit;
                 if (sr.ended) meta |= kS3Ended;
                 if (sr.timeout) meta |= kS3Timeout;
