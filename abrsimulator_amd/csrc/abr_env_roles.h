@@ -755,11 +755,15 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
     ABR_STAMP(8);
     if (v.pv.b_alive && v.pv.b_step < n_total && t >= 1) {
         const int32_t fl = m.flags[pb][l];
+        // the whole record in ONE round of LDS reads (as in role_p3_pre)
+        const int32_t r_step = m.step[pb][l], r_k = m.k_start[pb][l], r_a = m.action[pb][l], r_ndl = m.n_dl[pb][l],
+                      r_avail = m.avail_next[pb][l];
+        const double r_dl = m.dl[pb][l];
         // accept the download only if it started at exactly this lane's call-site tick
-        if ((fl & kRecValid) && m.step[pb][l] == v.pv.b_step && m.k_start[pb][l] == s.k) {
+        if ((fl & kRecValid) && r_step == v.pv.b_step && r_k == s.k) {
             const int64_t o = (int64_t)v.pv.b_step * p.n_lanes + i;
             float *obs = obs_out ? obs_out + (int64_t)v.pv.b_step * ABR_OBS_DIM * p.n_lanes : nullptr;
-            const int32_t a = m.action[pb][l];
+            const int32_t a = r_a;
             if (fl & kRecBadAct) {
                 v.done |= ABR_DONE_BADACT;
                 if (reward_out) ABR_OUT(reward_out[o], 0.0f);
@@ -768,11 +772,11 @@ __device__ __forceinline__ void role_p2_pre(P2Vars &v, const EnvParams &, SplitM
                 v.pv.b_alive = false;
             } else {
                 abrx::Download d;
-                d.dl = m.dl[pb][l]; d.n_dl = m.n_dl[pb][l]; d.hit = (fl & kRecHit) != 0;
+                d.dl = r_dl; d.n_dl = r_ndl; d.hit = (fl & kRecHit) != 0;
                 const int32_t prev_action = s.last_action;
                 const int32_t chunk = s.chunk_id;
                 ABR_STAMP(9);
-                const abrx::StepResult sr = abrx::lanej_after_download(s, tb, d, m.avail_next[pb][l], a);
+                const abrx::StepResult sr = abrx::lanej_after_download(s, tb, d, r_avail, a);
                 ABR_STAMP(13);
                 // everything the step reports from the tick tables -- the reward's two clocks and the observation's four -- in
                 // ONE burst of loads, consumed after the divisions below (this wave is the two-wave kernel's critical one: two
