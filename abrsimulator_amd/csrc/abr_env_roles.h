@@ -257,8 +257,11 @@ __device__ __forceinline__ void role_d_validate(DVars &v, SplitMail &m, const ab
     // everything the common cases look at in ONE round of LDS reads: this wave is on the iteration's critical path, and a read
     // issued only inside the branch that needs it is a round trip of its own (round 5: this and the same on the player's
     // side, +3.2 % at fuse 48, +2.2 % at fuse 20: profiles/r05_ab_fixed_costs.txt)
-    const int32_t f_alive = m.fb_alive[cb][l], f_step = m.fb_step[cb][l], f_k = m.fb_k[cb][l], f_pf = m.fb_pf[cb][l];
-    const double f_buf = m.fb_buf[cb][l];
+    int32_t f_alive = m.fb_alive[cb][l], f_step = m.fb_step[cb][l], f_k = m.fb_k[cb][l], f_pf = m.fb_pf[cb][l];
+    double f_buf = m.fb_buf[cb][l];
+    // "all five, now": without this the compiler sinks each read into the branch that uses it, a round trip apiece.  Only together
+    // with the same on the player's side does it show (+1.2 %; either alone -1 %: the two waves are level, profiles/r05_ab_fixed_costs.txt (5))
+    asm volatile("" : "+v"(f_alive), "+v"(f_step), "+v"(f_k), "+v"(f_pf), "+v"(f_buf));
     if (!f_alive) v.d_alive = false;
     else if (v.issued_step != f_step || v.issued_k != f_k) {
         // gated by buffer_full: take the player's word for where the download starts and
@@ -391,12 +394,13 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
     int32_t meta = 0;
     ABR_STAMP(8);
     if (v.b_alive && v.b_step < n_total && t >= 1) {
-        const int32_t fl = m.flags[pb][l];
+        int32_t fl = m.flags[pb][l];
         // the whole record in ONE round of LDS reads, not a second one behind the validity test (this wave is as critical as
         // the download wave)
-        const int32_t r_step = m.step[pb][l], r_k = m.k_start[pb][l], r_a = m.action[pb][l], r_ndl = m.n_dl[pb][l],
-                      r_avail = m.avail_next[pb][l];
-        const double r_dl = m.dl[pb][l];
+        int32_t r_step = m.step[pb][l], r_k = m.k_start[pb][l], r_a = m.action[pb][l], r_ndl = m.n_dl[pb][l],
+                r_avail = m.avail_next[pb][l];
+        double r_dl = m.dl[pb][l];
+        asm volatile("" : "+v"(fl), "+v"(r_step), "+v"(r_k), "+v"(r_a), "+v"(r_ndl), "+v"(r_avail), "+v"(r_dl));   // all seven, now (see role_d_validate)
         // accept the download only if it started at exactly this lane's call-site tick
         if ((fl & kRecValid) && r_step == v.b_step && r_k == s.k) {
             const int32_t a = r_a;
