@@ -32,7 +32,7 @@ SO_PATH = os.path.join(CSRC, "libabr_hip.so")
 if os.environ.get("ABR_HIP_LIB"):          # run everything on a diagnostic build (tools/, A/B scripts)
     SO_PATH = resolve(os.environ["ABR_HIP_LIB"])
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_RATES = 16
 MAX_HORIZON = 8
 OBS_DIM = 8
@@ -108,6 +108,8 @@ SYMBOLS = [
                                      _P, _P, _P, _P, _P, C.c_int64, _P]),
     ("abr_env_step_mpc", C.c_int, [_P, C.POINTER(MpcConfig), _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("abr_debug_chain", C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    ("abr_debug_selfcheck", C.c_int, [_P, _P, _P]),
+    ("abr_debug_drain", C.c_int, [C.c_double, C.c_double, _P, _P, C.c_int64, _P, _P, _P, C.POINTER(C.c_int32), _P]),
     ("abr_mpc_objective_grid", C.c_int, [C.POINTER(MpcConfig), C.c_int32, C.c_int32, C.c_double,
                                          _P, _P, _P, _P, _P]),
 ]

@@ -98,6 +98,7 @@ struct EnvParams {
     const double *GP;              // same for sd (aliases G when speed == 1)
     const int32_t *interval_tick;  // first tick k with int(G[k]/interval) >= j   (:158)
     const int32_t *avail_tick;     // first tick k with int(G[k]/L) - 1 >= c      (:143)
+    abrx::DrainTab drain;          // the per-binade cascade of buffer_level -= sd (abr_exact_jump.h); n == 0: none
     // traces (device, caller-owned)
     const double *traces;
     const int64_t *trace_off;
@@ -118,12 +119,36 @@ struct EnvParams {
     double *bw_hist;               // [V][n_lanes]
     double *ep_qoe_terms;          // [4][n_lanes]: rebuffer, startup, avg latency, bitrate variance of the last finished episode
     double *var_run;               // [n_lanes] sum of |br[a_i] - br[a_(i+1)]| over the running episode so far (:82), in its order
+    // abr_debug_selfcheck only (nullptr otherwise): a role-split kernel launched with this set writes 1 here if fresh_params()
+    // -- the parameter block re-read from the kernarg segment -- is THIS launch's block (it carries `sentinel`), 2 if not,
+    // and returns at once
+    uint32_t *selfcheck_out;
+    uint64_t sentinel;
 };
+
+// What a workspace says about itself, in its last 256 bytes: written by abr_env_create, compared by abr_env_notify_restore
+// (and by the Python wrapper's load_state_dict before it copies anything).  A checkpoint is a copy of the workspace, and the
+// layout of the regions in front of this tag changes between ABI versions (3: ep_actions gone, var_run added; 4: this tag):
+// restoring a workspace of another version, lane count or configuration would otherwise be reinterpreted with shifted
+// offsets and no error -- sizes can coincide.  kLayoutRev counts layout changes inside one ABI version.
+constexpr uint32_t kTagMagic = 0x57524241u;          // "ABRW"
+constexpr uint32_t kLayoutRev = 1;
+struct WorkspaceTag {
+    uint32_t magic, abi_version, layout_rev, n_rates;
+    int64_t n_lanes;
+    int32_t video_length, max_ticks, n_intervals, reserved_;
+    uint64_t total_bytes;
+    double chunk_length, interval, speed;            // the tick tables in front depend on these
+    uint8_t pad_[256 - 72];
+};
+static_assert(sizeof(WorkspaceTag) == 256, "the tag is one 256-byte block");
 
 struct abr_env {
     EnvParams p;
     abr_env_config cfg;
     size_t workspace_bytes;
+    void *tag_dev;                  // the workspace's layout tag (device) and what it must hold
+    WorkspaceTag tag;
     int impl;   // 3 = auto (default): see effective_impl(); 5 / 2 = role-split event-driven kernels, three / two waves
                 // per 64 lanes; 0 = event-driven, one thread per lane; 1 = tick-by-tick kernels (cross-check);
                 // 4 = asynchronous role pipeline (diagnostic build only)
@@ -540,7 +565,11 @@ __global__ __launch_bounds__(64) void env_advance_kernel(
 // ---------------------------------------------------------------------------
 using abrx::LaneJ;
 
-__device__ inline abrx::Tables make_tables(const EnvParams &p) {
+// cascade: whether the drains of this kernel go through the per-binade cascade (abr_exact_jump.h: drain_cascade) where it
+// applies.  Same results either way; measured per kernel (profiles/r06_ab_cascade.txt): +3.4 % for one thread per lane at
+// 1 M lanes, +2.5 % for the two-wave role split at 131 072 -- and -2 % for the three-wave kernel at 65 536, whose player
+// wave is not what an iteration waits for (fewer vector instructions, the same iteration time, more scalar traffic).
+__device__ inline abrx::Tables make_tables(const EnvParams &p, bool cascade = true) {
     abrx::Tables t;
     t.G = p.G; t.interval_tick = p.interval_tick; t.avail_tick = p.avail_tick;
     t.L = p.chunk_length; t.sd = p.sd; t.max_buffer = p.max_buffer;
@@ -548,6 +577,11 @@ __device__ inline abrx::Tables make_tables(const EnvParams &p) {
     t.per_lane_speed = p.lane_speeds != nullptr;
     t.speed_rows = p.lane_speeds ? p.speed_rows : 0;
     t.speed_stride = p.n_lanes; t.speeds = p.lane_speeds;
+    t.drain = p.drain;
+    if (p.lane_speeds || !cascade) t.drain.n = 0;      // per-lane speeds: every lane has a subtrahend of its own
+#ifdef ABR_NO_DRAIN_CASCADE
+    t.drain.n = 0;                 // A/B knob (tools/diag/csrc: make AB_FLAGS=-DABR_NO_DRAIN_CASCADE ab): round 5's drains
+#endif
     return t;
 }
 
@@ -856,6 +890,7 @@ struct Layout {
     size_t G, GP, interval_tick, avail_tick;        // table offsets
     size_t f64_state, i64_state, i32_state, u8_state, action_hist, bw_hist, ep_terms;
     size_t mpc_action, mpc_scratch;
+    size_t tag;                                      // the layout tag: the workspace's LAST 256 bytes (WorkspaceTag)
     size_t total;
     int32_t max_ticks, n_intervals;
 };
@@ -925,6 +960,7 @@ static int compute_layout(const abr_env_config *c, int64_t n_lanes, Layout *L) {
     L->ep_terms = o; o = align_up(o + sizeof(double) * 4 * N, A);
     L->mpc_action = o; o = align_up(o + sizeof(int32_t) * N, A);
     L->mpc_scratch = o; o = align_up(o + mpc_scratch_bytes_max(N), A);
+    L->tag = o; o = align_up(o + sizeof(WorkspaceTag), A);
     L->total = o;
     return ABR_OK;
 }
@@ -987,6 +1023,9 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
     p.G = (const double *)(w + L.G); p.GP = (const double *)(w + L.GP);
     p.interval_tick = (const int32_t *)(w + L.interval_tick);
     p.avail_tick = (const int32_t *)(w + L.avail_tick);
+    // buffer_level never exceeds max_buffer + chunk_length (a download only starts below max_buffer, :144); a level above
+    // the cascade would send its wave through the general chains (abr_lane_jump.h: lanej_drain)
+    p.drain = abrx::make_drain_tab(sd, cfg->max_buffer + cfg->chunk_length);
     p.traces = traces_dev; p.trace_off = trace_off_dev; p.trace_len = trace_len_dev;
     const size_t N = (size_t)n_lanes;
     double *f = (double *)(w + L.f64_state);
@@ -1017,6 +1056,15 @@ extern "C" int abr_env_create(const abr_env_config *cfg, const double *traces_de
 #undef UP
     he = hipMemsetAsync(w + L.f64_state, 0, L.total - L.f64_state, st);
     if (he == hipSuccess) he = hipMemsetAsync(p.done, ABR_DONE_EPISODE, N, st);  // not reset yet
+    {
+        WorkspaceTag &tg = e->tag;
+        memset(&tg, 0, sizeof(tg));
+        tg.magic = kTagMagic; tg.abi_version = ABR_ABI_VERSION; tg.layout_rev = kLayoutRev; tg.n_rates = (uint32_t)cfg->n_rates;
+        tg.n_lanes = n_lanes; tg.video_length = cfg->video_length; tg.max_ticks = mt; tg.n_intervals = L.n_intervals;
+        tg.total_bytes = L.total; tg.chunk_length = cfg->chunk_length; tg.interval = cfg->interval; tg.speed = cfg->speed;
+        e->tag_dev = w + L.tag;
+        if (he == hipSuccess) he = hipMemcpyAsync(e->tag_dev, &tg, sizeof(tg), hipMemcpyHostToDevice, st);
+    }
     if (he == hipSuccess) he = hipStreamSynchronize(st);   // host vectors die at return
     if (he != hipSuccess) { delete e; return fail(ABR_E_HIP, "workspace init: %s", hipGetErrorString(he)); }
     *env_out = e;
@@ -1094,9 +1142,28 @@ extern "C" int abr_env_set_bitrate_table(abr_env *env, const double *br_table_de
     return ABR_OK;
 }
 
-// the caller has copied a checkpointed workspace into this handle's workspace: episodes are in flight
+// the caller has copied a checkpointed workspace into this handle's workspace: episodes are in flight.  The copy must be what
+// this handle's abr_env_create would have laid out: the tag in its last 256 bytes says so (read back here: this call
+// synchronises the device, once per restore).
 extern "C" int abr_env_notify_restore(abr_env *env) {
     if (!env) return fail(ABR_E_INVALID, "env is NULL");
+    WorkspaceTag got;
+    HIP_TRY(hipDeviceSynchronize());           // the caller's copy may still be in flight on any stream
+    HIP_TRY(hipMemcpy(&got, env->tag_dev, sizeof(got), hipMemcpyDeviceToHost));
+    const WorkspaceTag &w = env->tag;
+    if (got.magic != kTagMagic)
+        return fail(ABR_E_WORKSPACE, "the restored workspace carries no layout tag: it was not written by this library at ABI "
+                    "version >= 4 (a version-2 / -3 checkpoint cannot be restored: the lane-state layout changed)");
+    if (got.abi_version != w.abi_version || got.layout_rev != w.layout_rev)
+        return fail(ABR_E_WORKSPACE, "the restored workspace was laid out by ABI version %u (layout %u), this library is %u (%u)",
+                    got.abi_version, got.layout_rev, w.abi_version, w.layout_rev);
+    if (got.n_lanes != w.n_lanes || got.video_length != w.video_length || got.n_rates != w.n_rates ||
+        got.max_ticks != w.max_ticks || got.n_intervals != w.n_intervals || got.total_bytes != w.total_bytes ||
+        got.chunk_length != w.chunk_length || got.interval != w.interval || got.speed != w.speed)
+        return fail(ABR_E_WORKSPACE, "the restored workspace belongs to another configuration: %lld lanes, %d chunks, %u rates, "
+                    "%d ticks, %llu bytes (this handle: %lld, %d, %u, %d, %llu)", (long long)got.n_lanes, got.video_length,
+                    got.n_rates, got.max_ticks, (unsigned long long)got.total_bytes, (long long)w.n_lanes, w.video_length,
+                    w.n_rates, w.max_ticks, (unsigned long long)w.total_bytes);
     apply_pending(env);
     env->armed = true;
     return ABR_OK;
@@ -2034,6 +2101,60 @@ extern "C" int abr_debug_chain(int32_t stop_kind, int32_t estimate_bias, const d
         case abrx::STOP_LT: return launch_chain_debug<abrx::STOP_LT>(estimate_bias, x0_dev, c_dev, thr_dev, n_dev, count, x_out_dev, a_out_dev, hit_out_dev, st);
         default: return fail(ABR_E_INVALID, "stop_kind must be 0 (>=), 1 (<=) or 2 (<)");
     }
+}
+
+// Diagnostic: the contract the role-split kernels' fresh_params() rests on -- `EnvParams p` is the FIRST by-value kernel
+// argument, so the block at offset 0 of the kernarg segment is this launch's parameter block -- checked in the PRODUCT build:
+// every instance of both kernels is launched once (one workgroup) with a sentinel in its parameter block and answers whether
+// fresh_params() saw it.  result_dev: uint32 [6] device memory, entry i = 1 (seen) or 2 (not) for
+// env_split3_kernel<1,2,3>, env_split_kernel<1,2,3>.  Touches no lane state.
+extern "C" int abr_debug_selfcheck(abr_env *env, uint32_t *result_dev, void *stream) {
+    if (!env || !result_dev) return fail(ABR_E_INVALID, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(result_dev, 0, 6 * sizeof(uint32_t), st));
+    EnvParams p = env->p;
+    p.sentinel = 0x5eed0000c0ffee00ull ^ (uint64_t)(uintptr_t)env;
+#define ABR_SC(k, slot)                                                                                          \
+    p.selfcheck_out = result_dev + (slot);                                                                          \
+    hipLaunchKernelGGL(k, dim3(1), dim3((slot) < 3 ? 192 : 128), 0, st, p, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0ull);
+    ABR_SC(env_split3_kernel<1>, 0) ABR_SC(env_split3_kernel<2>, 1) ABR_SC(env_split3_kernel<3>, 2)
+    ABR_SC(env_split_kernel<1>, 3) ABR_SC(env_split_kernel<2>, 4) ABR_SC(env_split_kernel<3>, 5)
+#undef ABR_SC
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
+}
+
+// Diagnostic: the drain of ONE subtrahend -- buffer_level -= speed*dt until <= 0 (Simulator.py:184, :194) -- as the kernels
+// run it (abr_lane_jump.h: lanej_drain: the per-binade cascade, or the general chain for a wave that holds a value above
+// it), one case per thread.
+__global__ void drain_debug_kernel(abrx::DrainTab tab, double sd, const double *__restrict__ x0,
+                                   const int32_t *__restrict__ n, int64_t count, double *__restrict__ x_out,
+                                   int32_t *__restrict__ a_out, uint8_t *__restrict__ hit_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    abrx::Tables t;
+    t.G = nullptr; t.interval_tick = nullptr; t.avail_tick = nullptr;
+    t.L = 0.0; t.sd = sd; t.max_buffer = 0.0; t.start_up_length = 0.0; t.V = 0; t.max_ticks = 0;
+    t.per_lane_speed = false; t.speed_rows = 0; t.speed_stride = 0; t.speeds = nullptr;
+    t.drain = tab;
+    double x = x0[i];
+    int32_t a = 0;
+    const bool zero = abrx::lanej_drain(t, x, sd, n[i], a);
+    x_out[i] = x; a_out[i] = a; hit_out[i] = zero ? 1 : 0;
+}
+
+extern "C" int abr_debug_drain(double sd, double max_level, const double *x0_dev, const int32_t *n_dev, int64_t count,
+                               double *x_out_dev, int32_t *a_out_dev, uint8_t *hit_out_dev, int32_t *stages_out,
+                               void *stream) {
+    if (!x0_dev || !n_dev || !x_out_dev || !a_out_dev || !hit_out_dev) return fail(ABR_E_INVALID, "NULL device pointer");
+    if (count < 1) return fail(ABR_E_INVALID, "count must be >= 1");
+    const abrx::DrainTab tab = abrx::make_drain_tab(sd, max_level);
+    if (stages_out) *stages_out = tab.n;
+    if (tab.n == 0) return fail(ABR_E_UNSUPPORTED, "no cascade for sd %g below %g: the kernels use the general chains", sd, max_level);
+    hipLaunchKernelGGL(drain_debug_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tab, sd,
+                       x0_dev, n_dev, count, x_out_dev, a_out_dev, hit_out_dev);
+    HIP_TRY(hipGetLastError());
+    return ABR_OK;
 }
 
 // Diagnostic: every combo evaluated from scratch by its own thread, literally as

@@ -32,6 +32,10 @@
 // (output stores go through ABR_OUT, abr_env.hip: non-temporal)
 
 // issue priorities of the three roles (s_setprio; A/B knobs: profiles/r03_ab_split3.txt, r05_experiments_not_kept.txt (3))
+// the three-wave kernel's drains: the general chains (0) or the per-binade cascade (1); see make_tables
+#ifndef ABR_SPLIT3_CASCADE
+#define ABR_SPLIT3_CASCADE 0
+#endif
 #ifndef ABR_PRIO_D
 #define ABR_PRIO_D 2
 #endif
@@ -93,11 +97,22 @@ __device__ __forceinline__ void lds_writes_done() {
 // pointers and constants -- would be live across the whole loop and spill; re-reading the block behind a compiler-only
 // fence keeps each role's scalar loads inside that role's part of the iteration (a dozen s_load per iteration).
 // CONTRACT: `EnvParams p` must stay the FIRST by-value argument of env_split3_kernel and env_split_kernel (the block is read
-// from offset 0 of the kernarg segment); both kernels check it against their own copy in the diagnostic stamps build.
+// from offset 0 of the kernarg segment).  The PRODUCT build can be asked: abr_debug_selfcheck launches every instance of both
+// kernels with a sentinel in the block and each answers whether fresh_params() saw it (tests/test_env_gpu.py); the diagnostic
+// stamps build also traps on a mismatch in every launch.
 __device__ __forceinline__ const EnvParams &fresh_params() {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     return *(const EnvParams *)kp;
+}
+
+// abr_debug_selfcheck (abr_env.hip): is the block fresh_params() reads this launch's own?  `p` is the kernel's by-value copy.
+__device__ __forceinline__ void selfcheck_answer(const EnvParams &p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const EnvParams &f = fresh_params();
+        *p.selfcheck_out = (f.sentinel == p.sentinel && f.selfcheck_out == p.selfcheck_out && f.n_lanes == p.n_lanes &&
+                            f.traces == p.traces && f.G == p.G) ? 1u : 2u;
+    }
 }
 
 // Loop-carried state.  The kernel body owns the loop, so a role's variables cannot be locals of a role loop any more.
@@ -388,7 +403,7 @@ __device__ __forceinline__ void role_p3_pre(PVars &v, const EnvParams &p, SplitM
                                             int32_t n_total, int32_t t, int cb2) {
     const int l = threadIdx.x & 63;
     const int cb = t & 1, pb = (t + 1) & 1;    // this iteration's / the previous one's slot
-    const abrx::Tables tb = make_tables(p);
+    const abrx::Tables tb = make_tables(p, ABR_SPLIT3_CASCADE != 0);
     const bool speeds = p.lane_speeds != nullptr;
     LaneJ &s = v.s;
     int32_t meta = 0;
@@ -664,6 +679,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __shared__ ActRing ring;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
+    if (p.selfcheck_out) { selfcheck_answer(p); return; }                            // abr_debug_selfcheck: every thread returns, before any barrier
 #ifdef ABR_SPLIT_STAMPS
     if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
 #endif
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     else { __builtin_amdgcn_s_setprio(ABR_PRIO_S); SVars v; role_s_begin(v, p, ring); s_park(park.s, v); }
     for (int32_t t = 0;; t++) {
         if (role == 0) {
-            if (t > 0) role_d_validate(dv, m, make_tables(p), t - 1);      // against what P published before the previous barrier
+            if (t > 0) role_d_validate(dv, m, make_tables(p, ABR_SPLIT3_CASCADE != 0), t - 1);      // against what P published before the previous barrier
             role_d_pre<MODE, true>(dv, p, m, &ring, actions, actions_out, n_total, seed, t);
         } else if (role == 1) {
             PVars v; p_unpark(park.p, v, p);
@@ -869,6 +885,7 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     __shared__ SplitMail m;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
+    if (p.selfcheck_out) { selfcheck_answer(p); return; }                            // abr_debug_selfcheck: every thread returns, before any barrier
 #ifdef ABR_SPLIT_STAMPS
     if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
 #endif

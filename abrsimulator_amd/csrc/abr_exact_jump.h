@@ -282,5 +282,135 @@ ABR_HD bool chain(double &x_io, double c, double thr, int32_t n, int32_t &a_out)
     return hit;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Drains with ONE constant for every lane: buffer_level -= speed*dt (Simulator.py:184) at one play speed.  (Round 6.)
+//
+// Going DOWN, the grid only refines, and that removes the "real addition" of a segment altogether.  Let x be a multiple
+// of u_e = 2^(e-52) (any x in binade e or e+1 is) and y = x - sd the exact difference.  If y >= 2^e the result is rounded
+// on the grid of binade e: fl(y) = x - S_e with S_e = RN(sd / u_e) * u_e (no tie: see make_drain_tab).  If y < 2^e it
+// is rounded on the grid of binade e-1, of which x is a multiple as well: fl(y) = x - S_(e-1).  So EVERY subtraction whose
+// exact result lies in binade e takes off exactly S_e -- the crossing step included -- and a drain is
+//     for e = top binade downwards:  n_e = steps whose exact result stays >= 2^e;   x -= n_e * S_e
+// with y >= 2^e  <=>  x - 2^e >= T_e := ceil(sd / u_e) * u_e (both sides multiples of u_e), hence
+//     n_e = floor((x - B_e) / S_e) + 1   if x >= B_e := 2^e + T_e,   else 0.
+// S_e and B_e depend on the binade only and are wave-uniform: S_e = fl(2^e + sd) - 2^e as in the header comment, T_e = S_e
+// or S_e + u_e.  A stage is a handful of exact float64 operations -- x - B_e, n * S_e and the remainder are multiples of
+// u_e below 2^53 u_e -- against the ~58 vector instructions of a chain_segment (estimate, three candidates, one real
+// addition), and a buffer that runs dry (the player wave's slowest case: six segments and a 16-tick plain tail) is one
+// pass over the binades and at most a few plain subtractions below them.  No table in memory: a first form read the stage
+// constants from one (scalar loads through the constant address space) and waited for a load in every stage -- the compiler
+// sinks a prefetch to its use -- which cost more than the six uniform instructions that compute them.
+// Bit-identical to the naive loop (tests/test_lane_jump_cpu.py fuzzes it on the host, tests/test_exact_jump_gpu.py on the device).
+struct DrainTab {
+    int32_t e_hi = 0;     // biased exponent of the top binade covered
+    int32_t n = 0;        // binades covered, downwards from e_hi; 0: no cascade (per-lane speeds, or a speed / range it does
+                          // not cover): the general chains do the drains
+    double top = 0.0;     // 2^(e_hi + 1): values at or above it lie above the cascade
+    double rcp = 0.0;     // 1 / sd: S_e differs from sd by less than 2^-40 of it in every binade covered, and the quotient
+                          // is settled with the exact remainder anyway
+};
+
+ABR_HD bool wave_any(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(v) != 0;
+#else
+    return v;
+#endif
+}
+
+// The cascade for subtrahend sd and values below max_level; n == 0 when it does not apply.  It ends above
+//   * the binade in which sd / u_e is a round-to-even TIE (the one whose half-ulp is sd's lowest set bit): there the step
+//     depends on the parity of x, and
+//   * 2 * 2^expo(sd): a step from binade e must land in binade e - 1, not lower.
+// Below it drain_cascade subtracts one tick at a time (a handful of ticks).
+ABR_HD DrainTab make_drain_tab(double sd, double max_level) {
+    DrainTab out;
+    if (!(sd > 0.0) || !(max_level > 0.0) || !(sd < 1.0e300) || !(max_level < 1.0e300)) return out;
+    const int es = expo(sd), eh = expo(max_level);
+    if (es < 64 || es > 1900 || eh > 1900) return out;               // subnormal / absurd ranges: not worth it
+    uint64_t bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+    bits = (uint64_t)__double_as_longlong(sd);
+#else
+    memcpy(&bits, &sd, 8);
+#endif
+    const uint64_t mant = (bits & 0xfffffffffffffull) | (1ull << 52);
+    int tz = 0;
+    while (!((mant >> tz) & 1)) tz++;
+    const int e_tie = es + 1 + tz;                                    // biased exponent of the tie binade
+    int e_lo = es + 2;
+    if (e_tie >= e_lo && e_tie <= eh) e_lo = e_tie + 1;
+    if (e_lo > eh) return out;
+    if (eh - e_lo + 1 > 64) return out;
+    // the quotient guess uses 1 / sd for 1 / S_e: its error is q^2 2^-54, which the +-1 settlement covers while q < 2^26
+    if (pow2_biased(eh) * 2.0 / sd >= 67108864.0) return out;
+    if (pow2_biased(e_lo) * 2.0 / sd > 64.0) return out;              // the plain tail below the cascade: at most ~64 ticks
+    out.e_hi = eh; out.n = eh - e_lo + 1;
+    out.top = pow2_biased(eh) * 2.0;
+    out.rcp = 1.0 / sd;
+    return out;
+}
+
+// Up to m subtractions of sd, stopping right after the first result <= 0: the contract of chain<STOP_LE>(x, -sd, 0.0, m, a).
+// `tb` must have been made for exactly this sd, and x must be below tb.top (the caller checks both).
+ABR_HD bool drain_cascade(const DrainTab &tb_in, double sd, double &x_io, int32_t m, int32_t &a_out) {
+    int32_t tb_n = tb_in.n, tb_e_hi = tb_in.e_hi;
+    double tb_rcp = tb_in.rcp;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The loop's two uniform constants live in VECTOR registers: the role kernels are short of scalar registers, and a
+    // constant the compiler re-reads from the kernel arguments inside the loop is a scalar-cache round trip per stage
+    // (measured: the cascade then loses to the chains it replaces).
+    asm volatile("" : "+v"(sd), "+v"(tb_rcp), "+v"(tb_n), "+v"(tb_e_hi));
+    tb_n = __builtin_amdgcn_readfirstlane(tb_n);       // the two loop bounds: scalar values of their own, not kernel-argument
+    tb_e_hi = __builtin_amdgcn_readfirstlane(tb_e_hi); // reloads
+#endif
+    double x = x_io;
+    int32_t a = 0;
+    int32_t i = 0;
+    // binades above every active lane's value: nothing to do there
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    while (i < tb_n && !wave_any((a < m) & (x >= pow2_biased(tb_e_hi - i)))) i++;
+    // from the wave's top binade downwards, while any lane has ticks left.  (A binade in which no active lane happens to
+    // have a step still costs its stage: the lanes of a wave spread over neighbouring binades, so such gaps are rare, and a
+    // test per stage costs every stage.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (; i < tb_n && wave_any(a < m); i++) {
+        const int e = tb_e_hi - i;                      // wave-uniform
+        const double base = pow2_biased(e);
+        const double u = pow2_biased(e - 52);
+        const double S = (base + sd) - base;             // RN(sd / u) * u (not a tie: make_drain_tab)
+        const double T = (S >= sd) ? S : S + u;          // ceil(sd / u) * u
+        const double B = base + T;
+        const double g = x - B;                          // exact (for a lane with a step here; others are masked by n <= 0)
+        int32_t q = sat_i32(g * tb_rcp);                // floor(g / S) give or take one (truncation towards zero)
+        const double r = g - (double)q * S;              // exact remainder of that guess
+        q -= (r < 0.0) ? 1 : 0;
+        q += (r >= S) ? 1 : 0;
+        int32_t n = q + 1;                               // g < 0: q <= -1 after the settlement, n <= 0
+        const int32_t left = m - a;                      // <= 0 for a lane that is done
+        n = n < left ? n : left;
+        n = n > 0 ? n : 0;
+        x = x - (double)n * S;                           // exact
+        a += n;
+    }
+    // below the cascade the grid is finer than sd's own ulp (or the one tie binade sits there): a few plain subtractions
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+#ifdef ABR_CASCADE_HOOK
+    const int32_t a_stages = a;
+#endif
+    while (a < m && x > 0.0) { x = x - sd; a++; }
+#ifdef ABR_CASCADE_HOOK
+    ABR_CASCADE_HOOK(tb_e_hi, tb_n, x_io, x, a_stages, a - a_stages, m);   // host-side analysis builds: binades visited, plain ticks
+#endif
+    x_io = x; a_out = a;
+    return a > 0 && x <= 0.0;
+}
+
 }  // namespace abrx
 #endif

@@ -63,6 +63,9 @@ struct Tables {
     int32_t speed_rows;
     int64_t speed_stride;
     const double *speeds;
+    // the per-binade cascade of buffer_level -= sd at THE one play speed (abr_exact_jump.h: drain_cascade); n == 0 with
+    // per-lane speeds or when the speed / buffer range is not covered: the general chains then do the drains
+    DrainTab drain;
 };
 
 // Where a lane is in its bandwidth trace.  Only the download side (phase A) reads it.
@@ -159,6 +162,19 @@ ABR_HD bool drain_to_zero(double &b_io, double sd, int32_t m, int32_t &a_out) {
     return a > 0 && b <= 0.0;
 }
 
+// The drain of the common case -- one play speed for every lane -- goes through the per-binade cascade (round 6: a stage
+// is ~25 vector instructions against the ~58 of a chain segment plus its loop, and a buffer that runs dry is one pass over
+// the binades instead of six segments and a 16-tick tail).  Wave-uniform choice: a lane above the cascade (never seen: it
+// covers max_buffer + chunk_length) sends the whole wave through the chains.
+ABR_HD bool lanej_drain(const Tables &t, double &b_io, double sd, int32_t m, int32_t &a_out) {
+    if (t.drain.n > 0 && !wave_any(!(b_io < t.drain.top))) {
+        const bool zero = drain_cascade(t.drain, sd, b_io, m, a_out);
+        ABR_STAMP(24);
+        return zero;
+    }
+    return drain_to_zero(b_io, sd, m, a_out);
+}
+
 // ---- speed schedule: the play speed changes at played-chunk boundaries ----
 // The first playing tick of a played chunk (play_length == 0) takes the chunk's speed
 // (:176-177); the chunk then lasts until play_length, `speed*dt` added per tick from 0, is
@@ -221,7 +237,7 @@ ABR_HD void lanej_idle(LaneJ &s, const Tables &t, int32_t m) {
         double b = s.buf;
         bool zero;
         if (t.speed_rows >= 2) zero = sched_drain<STOP_LE>(s, t, b, 0.0, m, a);
-        else { zero = drain_to_zero(b, s.sd, m, a); lanej_play(s, t, a); }     // :184,:194
+        else { zero = lanej_drain(t, b, s.sd, m, a); lanej_play(s, t, a); }       // :184,:194
         s.n_play += a;
         s.sumk += (long long)a * s.k + ((long long)a * (a - 1)) / 2;
         if (zero) { b = 0.0; s.be = true; s.n_rb += (m - a + 1); }             // :195-196, then :140
@@ -531,7 +547,7 @@ ABR_HD bool lanej_predict_next_call(double buf, int32_t k, int32_t n_dl, int32_t
     double b = buf;
     int32_t a = 0;
     // the ticks before the completing one (lanej_idle, playing branch)
-    if (n_dl > 1 && drain_to_zero(b, t.sd, n_dl - 1, a)) return false;
+    if (n_dl > 1 && lanej_drain(t, b, t.sd, n_dl - 1, a)) return false;
     // the completing tick (lanej_after_download): :170, :184, :190, :194
     b = b + t.L;
     b = b - t.sd;
@@ -545,7 +561,7 @@ ABR_HD bool lanej_predict_next_call(double buf, int32_t k, int32_t n_dl, int32_t
         if (w < 0) w = 0;
         if (w > mt - k) w = mt - k;
         if (w > 0) {
-            if (drain_to_zero(b, t.sd, w, a)) return false;
+            if (lanej_drain(t, b, t.sd, w, a)) return false;
             bf = b >= t.max_buffer;
             k += w;
         }

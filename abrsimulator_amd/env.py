@@ -126,6 +126,8 @@ class BatchedABREnv:
                 _lib.ptr(self.trace_len), self.n_traces, self.n_lanes, _lib.ptr(self.workspace),
                 nbytes.value, self._stream(), C.byref(h)))
         self._h = h
+        # the layout tag abr_env_create wrote into the workspace's last bytes, kept aside: what a state to be loaded must carry
+        self._tag = self.workspace[-self.TAG_BYTES:].clone()
         if lane_id_base:
             self._check(self.lib.abr_env_set_lane_id_base(self._h, int(lane_id_base)))
         impls = {"jump": 0, "tick": 1, "split": 2, "auto": 3, "async": 4, "split3": 5, "ring3": 6, "pair3": 7}
@@ -190,25 +192,33 @@ class BatchedABREnv:
 
         No device-to-host synchronisation happens here: a lane whose trace id is outside [0, n_traces) or whose start
         offset is negative is frozen ON THE DEVICE with ABR_DONE_BADARG in its done byte (the reference would raise
-        IndexError at Simulator.py:159).  check=True validates on the host first and raises ValueError instead -- at the
-        price of two synchronisations."""
+        IndexError at Simulator.py:159); the observation returned for it looks like a fresh lane's.  `done_after_reset()`
+        reads the lanes' done bytes as they stand (a zero-copy view, no step needed) so that a caller can see such lanes
+        without a step.  check=True validates on the host first and raises ValueError instead -- before this object or
+        the device state changes -- at the price of two synchronisations."""
         if trace_id is None:
             trace_id = torch.arange(self.n_lanes, device=self.device, dtype=torch.int32) % self.n_traces
-        self.trace_id = self._i32(trace_id, "trace_id")
+        tid = self._i32(trace_id, "trace_id")
         if start_offset is None:
             start_offset = torch.zeros(self.n_lanes, dtype=torch.int32, device=self.device)
-        self.start_offset = self._i32(start_offset, "start_offset")
-        if check:
-            if int(self.trace_id.min()) < 0 or int(self.trace_id.max()) >= self.n_traces:
+        off = self._i32(start_offset, "start_offset")
+        if check:                                  # before anything of this object changes
+            if int(tid.min()) < 0 or int(tid.max()) >= self.n_traces:
                 raise ValueError("trace_id out of range")
-            if int(self.start_offset.min()) < 0:
+            if int(off.min()) < 0:
                 raise ValueError("start_offset must be >= 0")
+        self.trace_id, self.start_offset = tid, off
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         self._call(self.lib.abr_env_reset, self._h, _lib.ptr(self.trace_id),
                    _lib.ptr(self.start_offset), _lib.ptr(m), _lib.ptr(self.obs))
         return self.obs
+
+    def done_after_reset(self):
+        """The lanes' done bytes as they stand in the workspace (uint8 [N], zero-copy): ABR_DONE_BADARG for a lane the last
+        reset() froze because of its trace id / start offset, 0 for a lane that is running."""
+        return self.mpc_inputs()[5]
 
     def step(self, actions):
         """One chunk per lane.  Returns (obs f32[OBS_DIM,N], reward f32[N], done u8[N]);
@@ -340,15 +350,29 @@ class BatchedABREnv:
                 self._view(v.hist_sum_inv, torch.float64, (N,)), self._view(v.done, torch.uint8, (N,)))
 
     # -- checkpoint / resume ------------------------------------------------
+    TAG_BYTES = 256     # the workspace's last 256 bytes: its layout tag (include/abr_env.h, ABI 4)
+
     def state_dict(self):
         """All simulator state is the workspace tensor (the reference keeps it in
-        run() locals and cannot checkpoint)."""
-        return dict(workspace=self.workspace.clone(), trace_id=self.trace_id, start_offset=self.start_offset)
+        run() locals and cannot checkpoint).  The dict is stamped with the ABI version and the
+        workspace size it was taken under; the workspace itself ends in the library's layout tag."""
+        return dict(workspace=self.workspace.clone(), trace_id=self.trace_id, start_offset=self.start_offset,
+                    abi_version=_lib.ABI_VERSION, workspace_bytes=int(self.workspace.numel()))
 
     def load_state_dict(self, sd):
-        if sd["workspace"].numel() != self.workspace.numel():
+        """Refuses -- before anything is copied -- a state that was taken under another ABI version (the lane-state layout
+        changes between versions; sizes can coincide), with another lane count or another configuration: the stamp of
+        state_dict() and the layout tag at the end of the saved workspace are compared with this handle's own."""
+        if sd.get("abi_version") != _lib.ABI_VERSION:
+            raise ValueError(f"state_dict was taken under ABI version {sd.get('abi_version')}, this library is version "
+                             f"{_lib.ABI_VERSION}: the workspace layout differs, the checkpoint cannot be restored")
+        w = sd["workspace"]
+        if w.numel() != self.workspace.numel() or sd.get("workspace_bytes") != self.workspace.numel():
             raise ValueError("workspace size mismatch: different config or lane count")
-        self.workspace.copy_(sd["workspace"])
+        if not torch.equal(w[-self.TAG_BYTES:].cpu(), self._tag.cpu()):
+            raise ValueError("workspace layout tag mismatch: the checkpoint belongs to another lane count, configuration "
+                             "or library version")
+        self.workspace.copy_(w)
         self.trace_id, self.start_offset = sd["trace_id"], sd["start_offset"]
         # the handle now carries episodes in flight (a freshly built one had none): the speeds /
         # bitrate table given to __init__ are in force, later setter calls are latched again

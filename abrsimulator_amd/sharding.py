@@ -128,7 +128,11 @@ class ShardStep:
     """What one launch of a ShardedABREnv returns: `local` -- this rank's outputs (dict obs [F, OBS_DIM, n], reward [F, n],
     done [F, n], actions [F, n] or None; views of the launch's slab, valid until the launch after next reuses it) -- and the
     handle to the ONE collective of the launch: gathered() -> (obs [world, OBS_DIM, n_max], reward [world, F, n_max]) of
-    every rank's final observation and rewards once the all-gather has finished; unsharded() the same in global lane order."""
+    every rank's final observation and rewards once the all-gather has finished; unsharded() the same in global lane order.
+    LIFETIME of what gathered() / unsharded() return: views of (or a concatenation made from) the double-buffered receive
+    buffer of the collective -- valid until the launch AFTER NEXT enqueues its all-gather into the same buffer on the side
+    stream; clone() what has to live longer, and read it on the stream gathered() was called on (that stream has waited for
+    the collective; another stream has not)."""
 
     def __init__(self, owner, buf, local, views):
         self._owner, self._buf, self.local, self._views = owner, buf, local, views
@@ -211,7 +215,10 @@ class ShardedABREnv:
         return lane_assignment(self.lane0, self.n_lanes, lens, xcd_groups=xcd_groups)
 
     def reset(self, trace_id=None, start_offset=None, mask=None):
-        """Default: the deterministic global-lane map (lane_assignment); or this shard's own trace ids / offsets."""
+        """Default: the deterministic global-lane map (lane_assignment); or this shard's own trace ids / offsets.
+        As BatchedABREnv.reset(): no host synchronisation; a lane with a trace id out of range or a negative offset is frozen
+        on the device with ABR_DONE_BADARG (visible in self.env.done_after_reset(), or in `done` after the next launch) while
+        its returned observation looks like a fresh lane's."""
         if trace_id is None:
             trace_id, start_offset = self.lane_map()
         tid = torch.as_tensor(trace_id)

@@ -37,7 +37,14 @@
 extern "C" {
 #endif
 
-/* 3: abr_env_has_impl (which implementations THIS build of the library carries: the product answers 0 for the rejected
+/* 4: the workspace carries a LAYOUT TAG in its last 256 bytes (magic, ABI version, lane count, configuration, size), written by
+ * abr_env_create; abr_env_notify_restore reads it back (it synchronises the device, once per restore) and answers
+ * ABR_E_WORKSPACE when the restored bytes were laid out by another ABI version or for another lane count / configuration --
+ * before this, such a workspace was reinterpreted with shifted offsets and no error.  abr_env_workspace_bytes grew by 256.
+ * CHECKPOINTS DO NOT CARRY OVER: a workspace saved under version 2 or 3 cannot be restored (version 3 itself changed the lane
+ * state -- ep_actions gone, a running variance sum added, 8 float64 state arrays -- without saying so; it has no tag and is
+ * refused).  New diagnostic entry points: abr_debug_drain, abr_debug_selfcheck.  No existing signature changed.
+ * 3: abr_env_has_impl (which implementations THIS build of the library carries: the product answers 0 for the rejected
  * pipelines 4, 6 and 7, which abr_env_set_impl refuses with ABR_E_UNSUPPORTED); under impl 3 (auto) a launch of ONE decision
  * resolves to 0 at every size (abr_env_get_effective_impl(fused = 0)); ABR_DONE_INTERNAL is reserved for the diagnostic
  * pipelines' watchdogs.  A version-2 host keeps working: nothing it could call changed its signature.
@@ -46,7 +53,7 @@ extern "C" {
  * shorter struct and must be rebuilt); since 1 also: workspace layout grew, abr_env_set_lane_speeds /
  * _speed_schedule / _bitrate_table are latched until the next full reset, every re-reset advances the
  * policy's episode counter, default impl is 3 (auto).  A host built against version 1 must be rebuilt. */
-#define ABR_ABI_VERSION 3
+#define ABR_ABI_VERSION 4
 #define ABR_MAX_RATES 16
 #define ABR_MAX_HORIZON 8
 
@@ -168,7 +175,10 @@ int abr_env_set_bitrate_table(abr_env *env, const double *br_table_dev);
 /* Resume: the whole simulator state is the workspace, so a checkpoint is a copy of it.  After copying
  * a checkpointed workspace into the workspace of a handle built with the same config, lane count
  * and (already set) speeds / bitrate table, call this: it marks the handle as carrying episodes in
- * flight, so that later setter calls are latched again. */
+ * flight, so that later setter calls are latched again.  It first reads the workspace's layout tag back
+ * (ABI 4; one device synchronisation) and returns ABR_E_WORKSPACE -- the handle then stays as it was, the
+ * workspace holds the foreign bytes and must be re-initialised by abr_env_reset of all lanes or restored
+ * again -- if the bytes were laid out by another ABI version, lane count or configuration. */
 int abr_env_notify_restore(abr_env *env);
 
 /* Which kernels serve reset/step: 2 = event-driven (exact closed-form stepping of the
@@ -405,6 +415,22 @@ int abr_mpc_objective_grid(const abr_mpc_config *cfg, int32_t chunk, int32_t pre
 int abr_debug_chain(int32_t stop_kind, int32_t estimate_bias, const double *x0_dev,
                     const double *c_dev, const double *thr_dev, const int32_t *n_dev, int64_t count,
                     double *x_out_dev, int32_t *a_out_dev, uint8_t *hit_out_dev, void *stream);
+
+/* Diagnostic: count independent drains "x <- fl(x - sd), up to n times, stop right after the first result that is <= 0" --
+ * buffer_level -= play_speed * dt, Simulator.py:184, :194 -- at ONE subtrahend sd for all cases, advanced on the device the way
+ * the environment kernels do when every lane plays at the same speed: by the per-binade cascade built for levels below
+ * max_level (csrc/abr_exact_jump.h: drain_cascade; abr_env_create builds it for max_buffer + chunk_length), or by the general
+ * chain for a wave that holds a value at or above the cascade's top.  Outputs per case as abr_debug_chain; *stages_out
+ * (nullable, host) = binades the cascade covers.  ABR_E_UNSUPPORTED when no cascade exists for (sd, max_level). */
+int abr_debug_drain(double sd, double max_level, const double *x0_dev, const int32_t *n_dev, int64_t count,
+                    double *x_out_dev, int32_t *a_out_dev, uint8_t *hit_out_dev, int32_t *stages_out, void *stream);
+
+/* Diagnostic: a self-check of the PRODUCT build's role-split kernels (impl 2 and 5).  Their service code re-reads the launch's
+ * parameter block from the kernel-argument segment every iteration instead of holding it in registers, which is only right
+ * while that block is the kernels' first argument; every instance of both kernels is launched once (one workgroup, no lane
+ * state touched) with a sentinel in the block and reports whether the re-read saw it.  result_dev: uint32 [6] device memory,
+ * 1 = seen, 2 = not seen, 0 = that launch never ran. */
+int abr_debug_selfcheck(abr_env *env, uint32_t *result_dev, void *stream);
 
 #ifdef __cplusplus
 }

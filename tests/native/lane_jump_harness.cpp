@@ -37,6 +37,29 @@ int64_t lj_drain_check(const double *b0, const double *sd, const int32_t *m, int
     return -1;
 }
 
+// drain_cascade (the per-binade cascade of ONE subtrahend, abr_exact_jump.h) against the same naive loop, n cases at the
+// subtrahend sd with the cascade made for levels below max_level, exactly as abr_env_create makes it.  Returns the index of
+// the first case that differs, -1 if none, -2 if no table exists for (sd, max_level); stats[0] = cases that ran dry,
+// stats[1] = stages of the table, stats[2] = cases above the table (skipped: the kernels send those through the chains)
+int64_t lj_cascade_check(double sd, double max_level, const double *b0, const int32_t *m, int64_t n, long long *stats) {
+    const abrx::DrainTab tb = abrx::make_drain_tab(sd, max_level);
+    stats[0] = 0; stats[1] = tb.n; stats[2] = 0;
+    if (tb.n == 0) return -2;
+    for (int64_t c = 0; c < n; c++) {
+        if (!(b0[c] < tb.top)) { stats[2]++; continue; }
+        double b = b0[c];
+        int32_t a = 0;
+        while (a < m[c] && b > 0.0) { b = b - sd; a++; }                    // the naive loop
+        const bool zero = a > 0 && b <= 0.0;
+        double bj = b0[c];
+        int32_t aj = 0;
+        const bool zj = abrx::drain_cascade(tb, sd, bj, m[c], aj);
+        if (zj != zero || aj != a || bj != b) return c;
+        stats[0] += zero ? 1 : 0;
+    }
+    return -1;
+}
+
 void lj_predict_stats(long long *out, int reset) {
     for (int i = 0; i < 5; i++) { out[i] = g_pred[i]; if (reset) g_pred[i] = 0; }
 }
@@ -52,6 +75,7 @@ void *lj_create(double interval, double L, double speed, int32_t V, double max_b
     c->t.L = L; c->t.sd = c->tt.sd; c->t.max_buffer = max_buffer; c->t.start_up_length = start_up_length;
     c->t.V = V; c->t.max_ticks = max_ticks; c->t.per_lane_speed = false;
     c->t.speed_rows = 0; c->t.speed_stride = 0; c->t.speeds = nullptr;
+    c->t.drain = abrx::make_drain_tab(c->tt.sd, max_buffer + L);     // as abr_env_create does
     c->n_rates = n_rates;
     for (int i = 0; i < n_rates; i++) c->ladder[i] = ladder[i];
     return c;
@@ -74,6 +98,7 @@ int lj_episode(void *h, const double *trace, int32_t tlen, int32_t offset, const
     s.cur.trace = trace; s.cur.tlen = tlen;
     s.sd = t.sd;
     if (lane_speed > 0.0) { t.per_lane_speed = true; s.sd = lane_speed * 0.01; }   // :182 product
+    if (lane_speed > 0.0 || sched) t.drain.n = 0;                                  // as make_tables does with per-lane speeds
     if (sched) { t.per_lane_speed = true; t.speed_rows = rows; t.speed_stride = 1; t.speeds = sched; s.lane = 0; }
     abrx::lanej_init(s, t, offset);
     if (!abrx::lanej_wait_call(s, t)) return -2;

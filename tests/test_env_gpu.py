@@ -638,3 +638,91 @@ def test_resume_into_a_freshly_built_env(oracle, impl):
     for k in fa:
         assert torch.equal(fa[k], fb[k]) and torch.equal(fb[k], fr[k]), k
     assert torch.equal(a.episode_qoe(), b.episode_qoe()) and torch.equal(b.episode_qoe(), ref.episode_qoe())
+
+
+def test_checkpoints_carry_a_layout_tag_and_foreign_ones_are_refused():
+    """a checkpoint is a copy of the workspace, whose layout changes between ABI versions while its size
+    can coincide.  ABI 4: the workspace ends in a layout tag (magic, ABI version, lane count, configuration, size) that
+    abr_env_notify_restore reads back, and state_dict() is stamped; a state of another version, lane count or configuration is
+    refused BEFORE anything is copied (Python) and by the library itself (a C host that copies the bytes anyway)."""
+    from abrsimulator_amd import _lib
+    meta, traces, trace_id, offset, actions = _random_case(seed=33, N=128, V=6)
+    env = make_env(meta, traces, 128, max_ticks=76800)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    env.step(torch.from_numpy(actions[:, 0].copy()).cuda())
+    sd = env.state_dict()
+    assert sd["abi_version"] == _lib.ABI_VERSION == 4 and sd["workspace_bytes"] == env.workspace.numel()
+    tag = sd["workspace"][-256:].cpu().numpy()
+    assert tag[:4].tobytes() == b"ABRW" and int(tag[4:8].view(np.uint32)[0]) == 4
+    before = env.workspace.clone()
+    # a state stamped with another ABI version (what a round-5 checkpoint would carry, had it carried a stamp) ...
+    for bad in (dict(sd, abi_version=3), {k: v for k, v in sd.items() if k != "abi_version"}):
+        with pytest.raises(ValueError, match="ABI version"):
+            env.load_state_dict(bad)
+    # ... one of another lane count (size differs) and one of the SAME size but another configuration (tag differs)
+    other = make_env(meta, traces, 192)
+    with pytest.raises(ValueError, match="size mismatch"):
+        env.load_state_dict(other.state_dict())
+    meta2 = dict(meta, chunk_length=meta["chunk_length"] * 0.5)
+    twin = make_env(meta2, traces, 128, max_ticks=76800)          # same tables' sizes, another chunk length
+    sd2 = twin.state_dict()
+    assert sd2["workspace"].numel() == env.workspace.numel()
+    with pytest.raises(ValueError, match="layout tag"):
+        env.load_state_dict(sd2)
+    assert torch.equal(env.workspace, before)                    # nothing was copied by any refused load
+    # the library's own check: a C host that copies foreign bytes in and calls abr_env_notify_restore
+    env.workspace[-256:].zero_()                                  # no tag at all: a pre-ABI-4 workspace
+    assert env.lib.abr_env_notify_restore(env._h) == -2           # ABR_E_WORKSPACE
+    assert b"layout tag" in env.lib.abr_last_error()
+    forged = sd["workspace"][-256:].clone()
+    forged[4] = 3                                                 # abi_version field: 3
+    env.workspace[-256:].copy_(forged)
+    assert env.lib.abr_env_notify_restore(env._h) == -2 and b"ABI version 3" in env.lib.abr_last_error()
+    forged = sd["workspace"][-256:].clone()
+    forged[16] = forged[16] + 1                                   # n_lanes field
+    env.workspace[-256:].copy_(forged)
+    assert env.lib.abr_env_notify_restore(env._h) == -2 and b"another configuration" in env.lib.abr_last_error()
+    env.load_state_dict(sd)                                       # the genuine one restores and steps on
+    o1 = env.step(torch.from_numpy(actions[:, 1].copy()).cuda())[0].clone()
+    env.load_state_dict(sd)
+    assert torch.equal(o1, env.step(torch.from_numpy(actions[:, 1].copy()).cuda())[0])
+
+
+def test_reset_validates_before_it_changes_anything_and_done_after_reset_shows_frozen_lanes():
+    """check=True raises BEFORE trace_id / start_offset of the object are overwritten (a later state_dict()
+    must not save the bad tensors); the sync-free default freezes a bad lane on the device, and done_after_reset() shows it
+    without a step."""
+    meta, traces, trace_id, offset, actions = _random_case(seed=34, N=128, V=6)
+    env = make_env(meta, traces, 128)
+    good_t, good_o = torch.from_numpy(trace_id), torch.from_numpy(offset)
+    env.reset(good_t, good_o)
+    kept_t, kept_o = env.trace_id.clone(), env.start_offset.clone()
+    bad_t = good_t.clone(); bad_t[9] = len(traces) + 3
+    bad_o = good_o.clone(); bad_o[11] = -5
+    for t_, o_ in ((bad_t, good_o), (good_t, bad_o)):
+        with pytest.raises(ValueError):
+            env.reset(t_, o_, check=True)
+        assert torch.equal(env.trace_id, kept_t) and torch.equal(env.start_offset, kept_o)
+    assert int(env.done_after_reset().sum()) == 0
+    env.reset(bad_t, bad_o)                                      # the default: no host synchronisation, lanes frozen on the device
+    d = env.done_after_reset().cpu().numpy()
+    assert d[9] == 8 and d[11] == 8 and (np.delete(d, [9, 11]) == 0).all()          # ABR_DONE_BADARG
+    _, _, dn = env.step(torch.from_numpy(actions[:, 0].copy()).cuda())
+    assert dn[9] == 8 and dn[11] == 8
+
+
+def test_product_kernels_answer_the_fresh_params_selfcheck():
+    """the role-split kernels' service code re-reads the launch's parameter block from the kernel-argument
+    segment (fresh_params(), csrc/abr_env_roles.h), which is right only while that block is the kernels' FIRST argument.
+    abr_debug_selfcheck asks every instance of both kernels in the PRODUCT build: each must have seen the sentinel."""
+    from abrsimulator_amd import _lib
+    meta, traces, trace_id, offset, actions = _random_case(seed=35, N=128, V=6)
+    env = make_env(meta, traces, 128)
+    env.reset(torch.from_numpy(trace_id), torch.from_numpy(offset))
+    before = env.workspace.clone()
+    res = torch.full((6,), 7, dtype=torch.int32, device="cuda")
+    _lib.check(env.lib.abr_debug_selfcheck(env._h, _lib.ptr(res), None))
+    torch.cuda.synchronize()
+    assert res.cpu().tolist() == [1, 1, 1, 1, 1, 1], res.cpu().tolist()
+    assert torch.equal(env.workspace, before)                    # no lane state touched
+    assert env.lib.abr_debug_selfcheck(None, _lib.ptr(res), None) == -1

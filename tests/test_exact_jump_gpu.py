@@ -96,6 +96,63 @@ def test_very_long_jumps_on_device(H):
     _both(H, H.fuzz_lt, LT, x1, -c1, np.array([1.5, 1.25, 1024.0, 2.0]), n1)
 
 
+def test_drain_cascade_on_device():
+    """The per-binade cascade of `buffer_level -= speed * dt` (round 6: csrc/abr_exact_jump.h: drain_cascade, what the
+    one-thread-per-lane and two-wave kernels drain with at one play speed) on the DEVICE against the plain loop on the host:
+    ticks, ran-dry answer and the float64 value, for the simulator's own subtrahend and others (exact binades, a tie binade
+    inside the range), starts on binade boundaries, on the stage thresholds, within ulps of k * sd, and -- mixed into the
+    same waves -- values above the cascade, which send their wave through the general chain."""
+    from abrsimulator_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(21)
+    n = 60_000
+    for sd, max_level in ((0.01, 24.0), (1.25 * 0.01, 24.0), (0.75 * 0.01, 9.0), (0.01, 1000.0), (0.0078125, 24.0),
+                          (0.01171875, 30.0), (0.5 * 0.01, 1.0e5)):
+        top = 2.0 ** np.floor(np.log2(max_level) + 1)
+        b_rand = rng.uniform(0.0, 1.0, n) ** 2 * min(max_level * 1.3, top * 1.2)       # some above the cascade
+        k = rng.integers(1, int(min(max_level, 60.0) / sd), n)
+        adv = k * sd
+        for _ in range(3):
+            adv = np.where(rng.random(n) < 0.5, np.nextafter(adv, np.where(rng.random(n) < 0.5, np.inf, -np.inf)), adv)
+        e = rng.integers(-8, int(np.log2(top)), n)
+        base = np.ldexp(1.0, e)
+        u = base * 2.0 ** -52
+        S = (base + sd) - base
+        T = np.where(S >= sd, S, S + u)
+        edge = np.where(rng.random(n) < 0.5, base, base + T) + rng.integers(-2, 3, n) * u
+        edge = np.where(rng.random(n) < 0.3, edge + rng.integers(0, 50, n) * S, edge)
+        sim = np.zeros(n)
+        for _ in range(4):
+            sim = sim + 4.0
+            t_ = rng.integers(0, 300, n)
+            for j in range(300):
+                sim = np.where(j < t_, sim - sd, sim)
+        B0 = np.concatenate([b_rand, adv, edge, sim])
+        M = np.concatenate([rng.integers(0, 3000, n), k + rng.integers(-2, 3, n), rng.integers(0, 5000, n), rng.integers(0, 2500, n)])
+        keep = B0 > 0.0
+        B0 = np.ascontiguousarray(B0[keep]); M = np.ascontiguousarray(np.maximum(M[keep], 0).astype(np.int32))
+        # the plain loop on the host, vectorised: one subtraction per round for the cases still running
+        xh = B0.copy(); ah = np.zeros(len(B0), np.int64)
+        run = (ah < M) & (xh > 0.0)
+        while run.any():
+            xh = np.where(run, xh - sd, xh); ah += run
+            run = (ah < M) & (xh > 0.0)
+        zh = (ah > 0) & (xh <= 0.0)
+        x0 = torch.from_numpy(B0).cuda(); nn = torch.from_numpy(M).cuda()
+        xo = torch.empty_like(x0); ao = torch.empty_like(nn); ho = torch.empty(len(B0), dtype=torch.uint8, device="cuda")
+        stages = C.c_int32(0)
+        _lib.check(lib.abr_debug_drain(sd, max_level, _lib.ptr(x0), _lib.ptr(nn), len(B0), _lib.ptr(xo), _lib.ptr(ao),
+                                       _lib.ptr(ho), C.byref(stages), None))
+        torch.cuda.synchronize()
+        xd, ad, hd = xo.cpu().numpy(), ao.cpu().numpy(), ho.cpu().numpy()
+        bad = np.flatnonzero((xd.view(np.uint64) != xh.view(np.uint64)) | (ad != ah) | (hd != zh))
+        assert bad.size == 0, (sd, max_level, bad[:3], B0[bad[:3]], M[bad[:3]], xd[bad[:3]], xh[bad[:3]], ad[bad[:3]], ah[bad[:3]])
+        assert stages.value >= 3 and zh.sum() > 10_000
+    one = C.c_void_p(256)
+    assert lib.abr_debug_drain(0.01, 1.0e12, one, one, 4, one, one, one, None, None) == -4      # ABR_E_UNSUPPORTED: no cascade
+    assert lib.abr_debug_drain(0.01, 24.0, None, one, 4, one, one, one, None, None) == -1
+
+
 def test_rejects_bad_arguments():
     from abrsimulator_amd import _lib
     lib = _lib.lib()

@@ -287,3 +287,64 @@ def test_drain_to_zero_against_the_plain_loop(H):
 
     assert check(b0, sd, m) > 50_000                     # random starts
     assert check(B0[n:], SD[n:], M[n:]) > 500_000         # near-multiples of sd and the sequence's own values
+
+
+def test_drain_cascade_against_the_plain_loop(H):
+    """drain_cascade (round 6: the per-binade table of `buffer_level -= speed * dt` at ONE play speed: every subtraction
+    whose exact result lies in binade e takes off exactly RN(sd / u_e) u_e, the crossing step included) against the plain
+    loop (Simulator.py:184, :194): the same ticks, the same ran-dry answer, the same float64 value -- for the simulator's own
+    sd, for speeds whose sd has trailing zero bits (exact binades, a tie binade inside the range), and for starts that sit
+    on binade boundaries, on the stage thresholds B_e = 2^e + ceil(sd / u_e) u_e, within ulps of k * sd, and on values the
+    rounded sequence itself visits on its way down."""
+    rng = np.random.default_rng(78)
+    H.lj_cascade_check.restype = C.c_int64
+    H.lj_cascade_check.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64,
+                                   C.POINTER(C.c_longlong)]
+    n = 120_000
+    total_dry = 0
+    for sd, max_level in ((0.01, 24.0), (1.25 * 0.01, 24.0), (0.75 * 0.01, 9.0), (0.01, 1000.0), (2.0 * 0.01, 64.0),
+                          (0.0078125, 24.0), (0.01171875, 30.0), (3.0 * 0.01, 5.0), (0.5 * 0.01, 1.0e5), (1.1 * 0.01, 24.0)):
+        top = 2.0 ** np.floor(np.log2(max_level) + 1)
+        b_rand = rng.uniform(0.0, 1.0, n) ** 2 * min(max_level * 1.2, top)
+        k = rng.integers(1, int(min(max_level, 60.0) / sd), n)
+        adv = k * sd
+        for _ in range(3):
+            adv = np.where(rng.random(n) < 0.5, np.nextafter(adv, np.where(rng.random(n) < 0.5, np.inf, -np.inf)), adv)
+        # binade boundaries and the stage thresholds, nudged by up to two ulps either way
+        e = rng.integers(-8, int(np.log2(top)), n)
+        base = np.ldexp(1.0, e)
+        u = base * 2.0 ** -52
+        S = (base + sd) - base
+        T = np.where(S >= sd, S, S + u)
+        edge = np.where(rng.random(n) < 0.5, base, base + T) + rng.integers(-2, 3, n) * u
+        edge = np.where(rng.random(n) < 0.3, edge + rng.integers(0, 50, n) * S, edge)
+        # values of the sequence run BACKWARDS from a tiny remainder
+        r = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-17, -9, n)
+        back = r.copy()
+        kk = rng.integers(1, 900, n)
+        for j in range(900):
+            back = np.where(j < kk, back + sd, back)
+        # sums of chunk lengths minus ticks, as the simulator's buffers are made
+        sim = np.zeros(n)
+        for _ in range(4):
+            sim = sim + 4.0
+            t_ = rng.integers(0, 300, n)
+            for j in range(300):
+                sim = np.where(j < t_, sim - sd, sim)
+        B0 = np.concatenate([b_rand, adv, edge, back, sim])
+        M = np.concatenate([rng.integers(0, 3000, n), k + rng.integers(-2, 3, n), rng.integers(0, 5000, n),
+                            kk + rng.integers(-2, 3, n), rng.integers(0, 2500, n)])
+        keep = B0 > 0.0
+        B0 = np.ascontiguousarray(B0[keep]); M = np.ascontiguousarray(np.maximum(M[keep], 0).astype(np.int32))
+        stats = (C.c_longlong * 3)()
+        bad = H.lj_cascade_check(sd, max_level, B0.ctypes.data_as(C.POINTER(C.c_double)),
+                                 M.ctypes.data_as(C.POINTER(C.c_int32)), len(B0), stats)
+        assert bad == -1, (sd, max_level, bad, None if bad < 0 else (B0[bad].hex(), int(M[bad])), list(stats))
+        assert stats[1] >= 3 and stats[2] < 0.2 * len(B0), (sd, max_level, list(stats))
+        total_dry += stats[0]
+    assert total_dry > 500_000
+    # no table where the cascade does not apply: the callers fall back to the chains
+    stats = (C.c_longlong * 3)()
+    z = np.zeros(1); zi = np.zeros(1, np.int32)
+    for sd, max_level in ((0.01, 1.0e12), (1.0e-320, 24.0), (0.01, 0.001)):
+        assert H.lj_cascade_check(sd, max_level, z.ctypes.data_as(C.POINTER(C.c_double)), zi.ctypes.data_as(C.POINTER(C.c_int32)), 1, stats) == -2
