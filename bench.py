@@ -22,22 +22,31 @@ Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchron
 sides, max over ranks.  When K < --min-timed-steps that region is repeated (`repeats`) and the
 median repeat is reported, every repeat bracketed the same way.
 
-At N = 1 the default run then adds, in the same JSON line: `selfcheck` (sampled lanes of the LAST TIMED launch replayed
-through the C oracle: observation rows, rewards, done; a mismatch fails the run), `sustained` (>= 1 s of back-to-back
-launches of the same shape in one bracket), `secondary` (MPC combos/s), `mpc_rollout` (abr_env_step_mpc on configs[2]
-and on configs[4]'s per-rank shape) and `strong_1048576`.
+Output (rank 0, stdout): the JSON line of the task's contract -- printed as soon as the headline is measured (at N = 1 together
+with `roofline`, `cpu_baseline` and `selfcheck`, so that this first line is already complete), then printed AGAIN, grown by one
+block, after each later block: `sustained`, `single_step`, `secondary`, `mpc_rollout`, `control` (N > 1), `strong_1048576`.  The
+LAST line is the complete one; a run that is killed half-way has left every earlier line.  A block that raises is recorded as
+{"error": ...} under its key and the run goes on (with more than one rank it then stops with exit code 3: the ranks must take
+the same path, and a failed collective has broken the process group).  Every phase runs under a watchdog: when a collective or a launch does not
+return within its bound (--phase-timeout; the process group itself is created with --dist-timeout) the rank says which phase
+and which rank on stderr and exits with code 124 -- a fresh process is the only retry.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline`
-(dominant kernel, HIP-event timed inside the timed region; `binding` = what limits it, from
-the committed SQ counters of the same kernel / lanes / fuse) and `cpu_baseline` (the C oracle
-on the host cores, bounded sample; rank 0, N=1 only; `affinity_cores` = cores visible,
-`cores` = threads used).
+`selfcheck` (N = 1): sampled lanes of the LAST TIMED launch replayed through the C oracle (observation rows, rewards, done); a
+mismatch fails the run.  `roofline`: dominant kernel, HIP-event timed inside the timed region; `binding` = what limits it, from
+the committed SQ counters of the same kernel / lanes / fuse.  `cpu_baseline`: the C oracle on the host cores, bounded sample;
+rank 0, N = 1 only; `affinity_cores` = cores visible, `cores` = threads used.
+
+Environment overrides: everything named ABR_BENCH_* (and ABR_XCD_GROUPS, ABR_HIP_LIB) that is set is listed in config.overrides;
+those that change the WORKLOAD (ABR_BENCH_MAX_BUFFER, _INTERVAL, _NTRACES, _STRONG_TOTAL, ABR_XCD_GROUPS) are refused unless
+--allow-overrides is given, so a line without `overrides` is BASELINE's workload.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
+from datetime import timedelta
 
 import numpy as np
 
@@ -45,11 +54,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LADDER = [0.3, 0.75, 1.2, 1.85, 2.85, 4.3]
-V, L, MAX_BUFFER, START_UP, INTERVAL = 48, 4.0, float(os.environ.get("ABR_BENCH_MAX_BUFFER", "20.0")), 8.0, float(os.environ.get("ABR_BENCH_INTERVAL", "1.0"))   # (the overrides are diagnostics: max_buffer 1e9 = buffer_full never gates a download; a longer trace interval = fewer constant changes per download)
+# (the overrides are diagnostics: max_buffer 1e9 = buffer_full never gates a download; a longer trace interval = fewer constant
+# changes per download; fewer traces = a cache-residency diagnostic; a smaller strong-scaling job for the 2-rank rehearsal test)
+V, L, START_UP = 48, 4.0, 8.0
+MAX_BUFFER = float(os.environ.get("ABR_BENCH_MAX_BUFFER", "20.0"))
+INTERVAL = float(os.environ.get("ABR_BENCH_INTERVAL", "1.0"))
 WEIGHTS = [4.3, 1.0, 1.0, 0.1]
-N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000   # (the override is a cache-residency diagnostic)
-STRONG_TOTAL = int(os.environ.get("ABR_BENCH_STRONG_TOTAL", "1048576"))   # configs[3] / north_star: the scaling
-                               # curve's job size (the override exists for the 2-rank rehearsal test)
+N_TRACES, TRACE_LEN = int(os.environ.get("ABR_BENCH_NTRACES", "1024")), 1000
+STRONG_TOTAL = int(os.environ.get("ABR_BENCH_STRONG_TOTAL", "1048576"))   # configs[3] / north_star: the scaling curve's job size
+WORKLOAD_OVERRIDES = ("ABR_BENCH_MAX_BUFFER", "ABR_BENCH_INTERVAL", "ABR_BENCH_NTRACES", "ABR_BENCH_STRONG_TOTAL", "ABR_XCD_GROUPS")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
@@ -57,7 +70,143 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 (FMA) x 2.4 
 # + the scalars around them): 5 f64 (incl. the running episode's bitrate-variance sum, round 5) + 1 i64 + 13 i32 + 2 u8
 STATE_BYTES = 5 * 8 + 8 + 13 * 4 + 2
 
+KERNELS = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>",
+           "ring3": "env_ring3_kernel<2>", "pair3": "env_pair3_kernel<2>", "jump": "env_jump_kernel<2>",
+           "tick": "env_advance_kernel<2>"}
 
+
+# =====================================================================================================================
+# harness: overrides, watchdog, progressive output, guarded blocks (no GPU needed: tests/test_bench_harness_cpu.py)
+# =====================================================================================================================
+def overrides_in_force(environ=None):
+    """Every override of the environment that is set: {name: value}."""
+    environ = os.environ if environ is None else environ
+    return {k: environ[k] for k in sorted(environ)
+            if (k.startswith("ABR_BENCH_") or k in ("ABR_XCD_GROUPS", "ABR_HIP_LIB")) and environ[k] != ""}
+
+
+def check_overrides(allow, environ=None):
+    """The overrides to record in config.overrides; raises SystemExit when one that changes the workload is set without
+    --allow-overrides (a line printed under it would be indistinguishable from BASELINE's workload)."""
+    ov = overrides_in_force(environ)
+    bad = [k for k in ov if k in WORKLOAD_OVERRIDES]
+    if bad and not allow:
+        raise SystemExit(f"bench.py: {', '.join(bad)} change(s) the workload; pass --allow-overrides to run a diagnostic "
+                         f"workload (the line then lists it under config.overrides)")
+    return ov
+
+
+class Watchdog:
+    """A thread that ends the process when a phase outlives its bound: a collective whose peer died or stalled, a launch
+    that never returns.  `with wd.phase("name", seconds): ...`; on expiry it prints which rank was in which phase for how
+    long (stderr) and exits with code 124 through os._exit -- the main thread may be inside a blocking C call, and a fresh
+    process is the only retry (no re-exec)."""
+
+    EXIT_CODE = 124
+
+    def __init__(self, rank=0, world=1, default_bound=150.0, poll=0.25, out=sys.stderr):
+        self.rank, self.world, self.default_bound, self.poll, self.out = rank, world, float(default_bound), poll, out
+        self._lock = threading.Lock()
+        self._stack = []                 # (name, deadline, started)
+        self.history = []                # phases that completed: (name, seconds)
+        self._stop = False
+        self._t = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self._t.start()
+
+    class _Phase:
+        def __init__(self, wd, name, bound):
+            self.wd, self.name, self.bound = wd, name, bound
+
+        def __enter__(self):
+            now = time.monotonic()
+            with self.wd._lock:
+                self.wd._stack.append((self.name, now + self.bound, now))
+            return self
+
+        def __exit__(self, *exc):
+            now = time.monotonic()
+            with self.wd._lock:
+                name, _, started = self.wd._stack.pop()
+                self.wd.history.append((name, now - started))
+            return False
+
+    def phase(self, name, bound=None):
+        return Watchdog._Phase(self, name, self.default_bound if bound is None else float(bound))
+
+    def current(self):
+        with self._lock:
+            return self._stack[-1][0] if self._stack else None
+
+    def stop(self):
+        self._stop = True
+
+    def _run(self):
+        while not self._stop:
+            time.sleep(self.poll)
+            now = time.monotonic()
+            with self._lock:
+                late = [(n, now - s, d) for n, d, s in self._stack if now > d]
+                stack = [n for n, _, _ in self._stack]
+            if late:
+                name, age, _ = late[0]
+                msg = {"error": "timeout", "rank": self.rank, "world": self.world, "phase": name, "phase_stack": stack,
+                       "seconds_in_phase": round(age, 1),
+                       "completed_phases": [n for n, _ in self.history][-8:],
+                       "note": "a collective or a launch did not return within its bound; every JSON line printed so far "
+                               "stands; start a fresh process to retry"}
+                try:
+                    self.out.write("bench.py watchdog: " + json.dumps(msg) + "\n")
+                    self.out.flush()
+                    sys.stdout.flush()
+                finally:
+                    os._exit(self.EXIT_CODE)
+
+
+class Emitter:
+    """The growing JSON line: emit() prints it (rank 0) and flushes, so that every block measured so far is on stdout whatever
+    happens next.  The last line printed is the complete one."""
+
+    def __init__(self, rank=0, out=sys.stdout):
+        self.rank, self.out, self.line, self.n_emitted = rank, out, {}, 0
+
+    def update(self, **kw):
+        self.line.update(kw)
+
+    def emit(self):
+        if self.rank == 0 and self.line:
+            self.out.write(json.dumps(self.line) + "\n")
+            self.out.flush()
+            self.n_emitted += 1
+
+
+def guarded(em, wd, key, fn, bound=None, keep_none=False, fatal=False):
+    """Runs one optional block under the watchdog; its result goes under `key` of the line, an exception becomes
+    {"error": ...} there (the headline and the blocks before it stand), and the grown line is printed.  fatal (more than one
+    rank): the ranks of a run must take the same path, and a collective that failed has broken the process group -- so the
+    error is recorded and printed as above, and then this rank exits with code 3 instead of going on to the next block."""
+    failed = False
+    try:
+        with wd.phase(key, bound):
+            res = fn()
+    except Exception as e:                              # noqa: BLE001 -- a block must not take the line down with it
+        import traceback
+        failed = True
+        res = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc(limit=3).strip().splitlines()[-3:]}
+    if res is not None or keep_none:
+        em.update(**{key: res})
+        em.emit()
+    if failed and fatal:
+        sys.stderr.write(f"bench.py: rank {wd.rank} of {wd.world}: block `{key}` failed ({res['error'][:300]}); with more than "
+                         f"one rank the run cannot go on -- every JSON line printed so far stands\n")
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(3)
+    return res
+
+
+# =====================================================================================================================
+# workload pieces shared with tools/ and tests/
+# =====================================================================================================================
 def synth_traces(mixed=False):
     rng = np.random.default_rng(0)
     if mixed:
@@ -242,7 +391,10 @@ def _load_traffic(workload, kernel, lanes, fuse):
     return None
 
 
-def main():
+# =====================================================================================================================
+# the run: one object holds what the blocks share; one method per block
+# =====================================================================================================================
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4800)
@@ -280,85 +432,124 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="env_random, N=1: capture one launch in a HIP graph and replay it "
                          "(removes the host launch path; matters at --fuse 1)")
-    a = ap.parse_args()
+    ap.add_argument("--allow-overrides", action="store_true",
+                    help="accept the ABR_BENCH_* / ABR_XCD_GROUPS overrides that change the workload (diagnostics); they are "
+                         "listed under config.overrides either way")
+    ap.add_argument("--dist-timeout", type=float, default=90.0,
+                    help="N>1: seconds the process group waits for a peer (rendezvous and every collective)")
+    ap.add_argument("--phase-timeout", type=float, default=150.0,
+                    help="seconds any single phase of the run (a timed region, a block) may take before the watchdog ends the "
+                         "process with exit code 124, saying which rank was in which phase")
+    return ap.parse_args(argv)
 
-    # ---- launcher environment first: nothing below may touch the GPU before this is settled ----
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
-    if a.total_lanes and a.total_lanes % world:
-        raise SystemExit("--total-lanes must divide evenly over the GPUs (equal gather shapes)")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: read when HSA initialises
-    # rehearsal knobs (a 1-GPU box cannot run RCCL with 2 ranks): ABR_BENCH_ONE_DEVICE=1 puts every
-    # rank on cuda:0, ABR_BENCH_BACKEND=gloo swaps the backend.  The driver's runs use neither.
-    if os.environ.get("ABR_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
 
-    import torch
-    import torch.distributed as dist
+class Run:
+    def __init__(self, a):
+        self.a = a
+        # ---- launcher environment first: nothing below may touch the GPU before this is settled ----
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if a.gpus != self.world and self.world > 1:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}")
+        if a.gpus > 1 and self.world == 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+        if a.total_lanes and a.total_lanes % self.world:
+            raise SystemExit("--total-lanes must divide evenly over the GPUs (equal gather shapes)")
+        self.overrides = check_overrides(a.allow_overrides)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: read when HSA initialises
+        # kernel arguments in device memory instead of host-coherent memory (read when HIP initialises): the role-split
+        # kernels re-read their parameter block inside the iteration loop; same box, interleaved: +2.5 % at 48 decisions
+        # per launch, +4.5 % at 20 (profiles/r06_ab_dev_kernarg.txt).  The package sets the same default on import.
+        os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+        # rehearsal knobs (a 1-GPU box cannot run RCCL with 2 ranks): ABR_BENCH_ONE_DEVICE=1 puts every
+        # rank on cuda:0, ABR_BENCH_BACKEND=gloo swaps the backend.  The driver's runs use neither.
+        if os.environ.get("ABR_BENCH_ONE_DEVICE") == "1":
+            self.local_rank = 0
+        self.wd = Watchdog(self.rank, self.world, a.phase_timeout)
+        self.em = Emitter(self.rank)
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    backend = "none"
-    # ABR_BENCH_FORCE_DIST=1: a ONE-rank process group, so that the RCCL code path (communicator,
-    # all_gather_into_tensor on the side stream, events) runs on a one-GPU box too
-    force_dist = world == 1 and os.environ.get("ABR_BENCH_FORCE_DIST") == "1"
-    if force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dist:
-        backend = os.environ.get("ABR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
+    # ---- process group, device, environment ----
+    def setup(self):
+        a = self.a
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.backend = "none"
+        # ABR_BENCH_FORCE_DIST=1: a ONE-rank process group, so that the RCCL code path (communicator,
+        # all_gather_into_tensor on the side stream, events) runs on a one-GPU box too
+        self.force_dist = self.world == 1 and os.environ.get("ABR_BENCH_FORCE_DIST") == "1"
+        if self.force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        self.distributed = self.world > 1 or self.force_dist
+        if self.distributed:
+            self.backend = os.environ.get("ABR_BENCH_BACKEND", "nccl")
+            to = timedelta(seconds=a.dist_timeout)
+            with self.wd.phase("init_process_group", a.dist_timeout + 30):
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev, timeout=to)      # "nccl" IS RCCL on ROCm
+                else:
+                    dist.init_process_group(self.backend, timeout=to)
+
+        import abrsimulator_amd as A
+        from abrsimulator_amd._lib import OBS_DIM
+        from abrsimulator_amd.sharding import shard_range
+        self.A, self.OBS_DIM, self.shard_range = A, OBS_DIM, shard_range
+        if a.total_lanes:
+            self.lane0, self.N = shard_range(a.total_lanes, self.world, self.rank)       # strong scaling
         else:
-            dist.init_process_group(backend)
+            self.N = a.lanes_per_gpu                                                     # weak scaling (default)
+            self.lane0 = self.rank * self.N
+        self.traces = synth_traces(a.mixed_traces)
+        tid, off = lane_assignment(self.lane0, self.N, self.traces)
+        self.mpd = A.MPD(V, L, MAX_BUFFER, START_UP, A.Chunk(LADDER))
+        self.env = A.BatchedABREnv(self.mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, self.traces), self.N,
+                                   device=self.dev, auto_reset=True, lane_id_base=self.lane0, impl=a.impl)
+        self.env.reset(torch.from_numpy(tid), torch.from_numpy(off))
+        self.K, self.W = a.steps, a.warmup
+        self.repeats = max(1, -(-a.min_timed_steps // self.K)) if self.K < a.min_timed_steps else 1
 
-    import abrsimulator_amd as A
-    from abrsimulator_amd._lib import OBS_DIM
-    from abrsimulator_amd.sharding import ShardedABREnv, shard_range
+    def barrier(self):
+        """dist.barrier (bounded by the process group's timeout and by the watchdog phase around the caller) + synchronize."""
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
 
-    if a.total_lanes:
-        lane0, N = shard_range(a.total_lanes, world, rank)       # strong scaling
-    else:
-        N = a.lanes_per_gpu                                      # weak scaling (default)
-        lane0 = rank * N
-    traces = synth_traces(a.mixed_traces)
-    tid, off = lane_assignment(lane0, N, traces)
-    mpd = A.MPD(V, L, MAX_BUFFER, START_UP, A.Chunk(LADDER))
-    env = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), N, device=dev,
-                          auto_reset=True, lane_id_base=lane0, impl=a.impl)
-    env.reset(torch.from_numpy(tid), torch.from_numpy(off))
-    KERNELS = {"async": "env_async_kernel<2>", "split": "env_split_kernel<2>", "split3": "env_split3_kernel<2>", "ring3": "env_ring3_kernel<2>", "pair3": "env_pair3_kernel<2>",
-               "jump": "env_jump_kernel<2>", "tick": "env_advance_kernel<2>"}
-    impl = env.effective_impl(fused=True)      # what the library resolves --impl to for fused rollouts
-    env_kernel = KERNELS[impl]                 # (re-read below once the decisions per launch are known)
+    def timed_region(self, runner, n_steps):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks."""
+        torch, dist = self.torch, self.dist
+        self.barrier()
+        t0 = time.perf_counter()
+        runner(n_steps, True)
+        self.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
+        if self.distributed:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
 
-    def barrier():
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    @staticmethod
+    def launch_stats(events):
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+        return float(np.mean(ms)) * 1e-3, float(np.mean([f for _, _, f in events]))
 
-    K, W = a.steps, a.warmup
-    ev = []
-    gat = None
-
-    def mpc_setup():
-        player = A.EnvPlayer(env, mpd=A.MPD(V, L, MAX_BUFFER, START_UP,
-                                            [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
+    # ---- runners ----
+    def mpc_setup(self):
+        A, a = self.A, self.a
+        player = A.EnvPlayer(self.env, mpd=A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
                              qoe=A.QOEMetric(4.3, 1.0, 0.0))
-        ctl = A.BatchedMPCController(player, horizon=5, clip_horizon=True, device=dev)
+        ctl = A.BatchedMPCController(player, horizon=5, clip_horizon=True, device=self.dev)
         # give every lane a history first (the reference divides by zero on an empty one, D13)
-        env.step_random(3, a.seed)
-        return player, ctl, player.hist_n.clone(), player.hist_sum_inv.clone()
+        self.env.step_random(3, a.seed)
+        return player, ctl
 
-    def mpc_runner(player, ctl, hist_n0, hist_s0, events, drive_env):
-        mpc_out = dict(obs=torch.empty(1, OBS_DIM, N, dtype=torch.float32, device=dev),
+    def mpc_runner(self, ctl, events, drive_env):
+        torch, N, dev = self.torch, self.N, self.dev
+        mpc_out = dict(obs=torch.empty(1, self.OBS_DIM, N, dtype=torch.float32, device=dev),
                        reward=torch.empty(1, N, dtype=torch.float32, device=dev),
                        done=torch.empty(1, N, dtype=torch.uint8, device=dev), actions=None)
 
@@ -369,7 +560,7 @@ def main():
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 if drive_env:
-                    env.step_mpc(ctl, 1, out=mpc_out)       # K3 + K1 on the device, no host glue
+                    self.env.step_mpc(ctl, 1, out=mpc_out)       # K3 + K1 on the device, no host glue
                 else:
                     ctl.next_bitrate()
                 if timed:
@@ -377,16 +568,21 @@ def main():
                     events.append((e0, e1, 1))
         return run
 
-    def make_random_runner(env_, N_, F_, events_, use_graph, gather_on=True, total_=None, lane0_=None):
+    def make_random_runner(self, env_, N_, F_, events_, use_graph, gather_on=True, total_lanes=None):
         """The env_random step loop over `env_`, through the package's ShardedABREnv (abrsimulator_amd/sharding.py): launches
         of F_ fused decisions into double-buffered slabs; with more than one rank THE one collective of the path per launch
         -- ONE all-gather of the packed slab [final observation (8 x N) | rewards (F x N)] on a side stream, overlapped with
         the next launch.  The intermediate observations of a fused launch are consumed on-device by the built-in policy and
-        stay in the local slab; at --fuse 1 every observation is gathered (configs[3] literally)."""
-        gather = (world > 1 or force_dist) and not a.no_gather and gather_on
-        sh = ShardedABREnv(None, None, env_.network_info, lanes_per_rank=N_, fuse=F_, device=dev, gather=gather, env=env_,
-                           rank=rank, world=world)
-        assert sh.n_lanes == N_
+        stay in the local slab; at --fuse 1 every observation is gathered (configs[3] literally).
+        total_lanes: the job's size under STRONG scaling, so that uneven shards agree on the largest one (the staging
+        buffer and the all-gather's size); None = weak scaling, every rank holds N_ lanes."""
+        from abrsimulator_amd.sharding import ShardedABREnv
+        torch, a, dev = self.torch, self.a, self.dev
+        gather = self.distributed and not a.no_gather and gather_on
+        kw = dict(total_lanes=total_lanes) if total_lanes else dict(lanes_per_rank=N_)
+        sh = ShardedABREnv(None, None, env_.network_info, fuse=F_, device=dev, gather=gather, env=env_,
+                           rank=self.rank, world=self.world, **kw)
+        assert sh.n_lanes == N_, (sh.n_lanes, N_)
         gat_ = sh._gather
         graph = None
         if use_graph:
@@ -401,6 +597,7 @@ def main():
 
         pool = []      # HIP events are created on their first record(): do that outside the timed region
         info = dict(n_done=0, last=None, bufs=sh._outs, sharded=sh)     # decisions run so far; (buffer, decisions, first decision) of the last launch
+        K = self.K
 
         def take():
             return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
@@ -434,126 +631,81 @@ def main():
         run_.info = info
         return run_, gat_
 
-    if a.workload == "env_random":
-        F1 = max(1, min(a.fuse, K))           # decisions fused into one launch at N = 1 (what BENCH runs)
-        F = F1
-        if ((world > 1 or force_dist) and not a.no_gather and not a.no_split_launch and K <= a.fuse and K >= 2
-                and K % 2 == 0):
-            # more than one rank and the whole timed region would be ONE launch: its all-gather would have
-            # nothing to hide behind (the bracket closes right after it).  Two launches of K/2 decisions put
-            # the first gather under the second launch; only the second, smaller one stays exposed.  (Even K
-            # only: both launches then use the pre-bound slabs and both are gathered.)  The `control` block of
-            # the JSON line separates what this change of launch shape costs from what the collective costs.
-            F = K // 2
-        impl = env.effective_impl(fused=F > 1)     # launches of ONE decision resolve differently (abr_env.h)
-        env_kernel = KERNELS[impl]
-        run, gat = make_random_runner(env, N, F, ev, a.graph and world == 1)
-        units_per_step = N * world
-        unit, metric = "env-steps/s", "env_steps_per_sec"
-    else:
-        F = 1
-        impl = env.effective_impl(fused=False) if a.workload == "env_mpc" else None   # env_mpc launches K1 one decision at a time; `mpc` launches no env kernel
-        player, ctl, hn0, hs0 = mpc_setup()
-        run = mpc_runner(player, ctl, hn0, hs0, ev, a.workload == "env_mpc")
-        if a.workload == "mpc":
-            units_per_step = N * world * 6 ** 5
-            unit, metric = "combos/s", "mpc_combos_per_sec"
+    # ---- block: the headline ----
+    def headline(self):
+        a, K, W = self.a, self.K, self.W
+        self.ev = []
+        self.gat = None
+        self.F1 = self.F = 1
+        if a.workload == "env_random":
+            self.F1 = max(1, min(a.fuse, K))           # decisions fused into one launch at N = 1 (what BENCH runs)
+            self.F = self.F1
+            if (self.distributed and not a.no_gather and not a.no_split_launch and K <= a.fuse and K >= 2 and K % 2 == 0):
+                # more than one rank and the whole timed region would be ONE launch: its all-gather would have
+                # nothing to hide behind (the bracket closes right after it).  Two launches of K/2 decisions put
+                # the first gather under the second launch; only the second, smaller one stays exposed.  (Even K
+                # only: both launches then use the pre-bound slabs and both are gathered.)  The `control` block of
+                # the JSON line separates what this change of launch shape costs from what the collective costs.
+                self.F = K // 2
+            self.impl = self.env.effective_impl(fused=self.F > 1)     # launches of ONE decision resolve differently (abr_env.h)
+            self.env_kernel = KERNELS[self.impl]
+            self.run, self.gat = self.make_random_runner(self.env, self.N, self.F, self.ev, a.graph and self.world == 1,
+                                                         total_lanes=a.total_lanes or None)
+            self.units_per_step = self.N * self.world if not a.total_lanes else a.total_lanes
+            self.unit, self.metric = "env-steps/s", "env_steps_per_sec"
         else:
-            units_per_step = N * world
-            unit, metric = "env-steps/s", "env_steps_per_sec_mpc_policy"
+            # env_mpc launches K1 one decision at a time; `mpc` launches no env kernel
+            self.impl = self.env.effective_impl(fused=False) if a.workload == "env_mpc" else None
+            self.env_kernel = None
+            _, ctl = self.mpc_setup()
+            self.run = self.mpc_runner(ctl, self.ev, a.workload == "env_mpc")
+            if a.workload == "mpc":
+                self.units_per_step = self.N * self.world * 6 ** 5
+                self.unit, self.metric = "combos/s", "mpc_combos_per_sec"
+            else:
+                self.units_per_step = self.N * self.world
+                self.unit, self.metric = "env-steps/s", "env_steps_per_sec_mpc_policy"
+        with self.wd.phase("warmup"):
+            self.run(W, False)
+        self.times = []
+        for r in range(self.repeats):
+            with self.wd.phase(f"timed_region[{r}]"):
+                self.times.append(self.timed_region(self.run, K))
+        self.elapsed = float(np.median(self.times))
+        self.avg_launch_s, self.f_per_launch = self.launch_stats(self.ev)
+        roof = self.env_roofline() if a.workload == "env_random" else self.mpc_roofline(self.avg_launch_s)
+        gathering = self.distributed and not a.no_gather and a.workload == "env_random"
+        F, N = self.F, self.N
+        config = {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": self.units_per_step if a.workload != "mpc" else N * self.world,
+                  "fuse": F, "launches_per_region": -(-K // F), "fuse_at_n1": self.F1 if a.workload == "env_random" else 1,
+                  "impl": self.impl,
+                  "history_restore": False if a.workload != "env_random" else None,
+                  "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
+                  "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
+                  "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
+                  "hip_graph": bool(a.graph and self.world == 1 and a.workload == "env_random"),
+                  "auto_reset": True,
+                  "collective": (f"1 all_gather_into_tensor per launch of the packed slab [final obs 8xN | "
+                                 f"rewards {F}xN] float32 = {(8 + F) * N * 4} B per rank, overlapped "
+                                 f"with the next launch; backend {self.backend}; issued "
+                                 f"{self.gat.n_collectives if self.gat else 0}x" if gathering else "none")}
+        if self.overrides:
+            config["overrides"] = self.overrides
+        self.em.update(metric=self.metric, value=self.units_per_step * K / self.elapsed, unit=self.unit, n_gpus=self.world,
+                       steps=K, warmup=W, ms_per_step=self.elapsed / K * 1e3, higher_is_better=True,
+                       scaling="strong" if a.total_lanes else "weak", vs_baseline=None, dtype="f64", data="synthetic",
+                       repeats=self.repeats, repeat_seconds=self.times, config=config, roofline=roof, cpu_baseline=None)
 
-    def timed_region(runner, n_steps):
-        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks."""
-        barrier()
-        t0 = time.perf_counter()
-        runner(n_steps, True)
-        barrier()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1 or force_dist:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        return float(el.item())
-
-    run(W, False)
-    repeats = max(1, -(-a.min_timed_steps // K)) if K < a.min_timed_steps else 1
-    times = [timed_region(run, K) for _ in range(repeats)]
-    elapsed = float(np.median(times))
-
-    def launch_stats(events):
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
-        return float(np.mean(ms)) * 1e-3, float(np.mean([f for _, _, f in events]))
-
-    avg_launch_s, f_per_launch = launch_stats(ev)
-
-    # ---- self-check, part 1 (N = 1): keep what the LAST TIMED launch wrote for a sample of lanes -- its observation rows,
-    #      rewards and done bytes -- before anything overwrites the slab.  Part 2 replays those lanes through the oracle in
-    #      the cpu_baseline leg below and puts the verdict into the line; a mismatch fails the run. ----
-    selfcheck_in = None
-    if a.workload == "env_random" and world == 1 and not a.no_cpu_baseline and getattr(run, "info", None) and run.info["last"]:
-        b_, f_, n0_ = run.info["last"]
-        rng_ = np.random.default_rng(5)
-        pick = np.unique(np.concatenate([np.arange(8), np.arange(N - 8, N), [63, 64, 127, 128],
-                                         rng_.integers(0, N, 300)])).astype(np.int64)
-        pick = pick[(pick >= 0) & (pick < N)]
-        pk = torch.from_numpy(pick).to(dev)
-        bo = run.info["bufs"][b_]
-        selfcheck_in = dict(pick=pick, n0=n0_, f=f_, obs=bo["obs"][:f_].index_select(2, pk).cpu().numpy(),
-                            reward=bo["reward"][:f_].index_select(1, pk).cpu().numpy(),
-                            done=bo["done"][:f_].index_select(1, pk).cpu().numpy())
-
-    # ---- sustained (N = 1): at least a second of back-to-back launches of the SAME shape in ONE bracket, so that clocks and
-    #      thermals have settled and an outside sampler sees the GPU busy; the headline above stays what it was ----
-    sustained = None
-    if a.workload == "env_random" and world == 1 and not a.no_sustained and getattr(run, "info", None):
-        n_l = int(np.ceil(a.sustained_seconds * 1.1 / max(avg_launch_s, 1e-6)))
-        per_mark = max(1, int(0.1 / max(avg_launch_s, 1e-6)))          # an event every ~100 ms
-        bufs_ = run.info["bufs"]
-        marks = []
-        barrier()
-        t0 = time.perf_counter()
-        for j in range(n_l):
-            if j % per_mark == 0:
-                e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((j, e))
-            env.step_random(F, a.seed, out=bufs_[j & 1])
-        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((n_l, e))
-        barrier()
-        el_s = time.perf_counter() - t0
-        run.info["n_done"] += n_l * F; run.info["last"] = None
-        win = [(j1 - j0) * F * N / (e0.elapsed_time(e1) * 1e-3) for (j0, e0), (j1, e1) in zip(marks[:-1], marks[1:])
-               if j1 - j0 == per_mark]
-        sustained = {"value": N * F * n_l / el_s, "unit": unit, "seconds": el_s, "launches": n_l, "fuse": F,
-                     "ms_per_step": el_s / (n_l * F) * 1e3,
-                     "first_100ms_value": win[0] if win else None, "last_100ms_value": win[-1] if win else None,
-                     "last_over_first": (win[-1] / win[0]) if len(win) >= 2 else None,
-                     "windows_100ms": len(win), "min_window_value": min(win) if win else None,
-                     "note": "one bracket (barrier + synchronize on both sides) around all launches; the windows are HIP "
-                             "events recorded every ~100 ms inside it"}
-
-    # ---- the reset()/get_video_chunk(quality) surface itself (N = 1): ONE decision per launch with the caller's actions,
-    #      abr_env_step (Simulator.py:155's call site turned inside out) ----
-    single_step = None
-    if a.workload == "env_random" and world == 1 and not a.no_single_step:
-        acts1 = torch.randint(0, len(LADDER), (N,), dtype=torch.int32, device=dev)
-        for _ in range(50):
-            env.step(acts1)
-        n1 = 400
-        barrier(); t0 = time.perf_counter()
-        for _ in range(n1):
-            env.step(acts1)
-        barrier()
-        el1 = time.perf_counter() - t0
-        single_step = {"metric": "env_steps_per_sec_single_decision_launches", "value": N * n1 / el1, "unit": "env-steps/s",
-                       "launches": n1, "us_per_launch": el1 / n1 * 1e6, "impl": env.effective_impl(fused=False),
-                       "call": "abr_env_step(actions): one decision per launch, caller-supplied actions (a fixed random vector)"}
-
-    def env_roofline():
+    def env_roofline(self):
         # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
         # launch; per decision: obs 32 + reward 4 + done 1 out, previous_bitrates 1 +
         # previous_bandwidths 8 appended, and the trace points walked (8 B bandwidth + 4 B
         # interval-end tick each; 407 ticks/decision at interval 1 s -> 4.07 points).
+        N, f_per_launch, avg_launch_s = self.N, self.f_per_launch, self.avg_launch_s
         pts = 4.07 * (8 + 4)
         per_decision = 32 + 4 + 1 + 1 + 8 + pts
         alg_bytes = N * (2 * STATE_BYTES + f_per_launch * per_decision)
-        roof = dict(bound="hbm", kernel=env_kernel,
+        roof = dict(bound="hbm", kernel=self.env_kernel,
                     achieved=alg_bytes / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     traffic=None, avg_launch_us=avg_launch_s * 1e6,
                     algorithmic_bytes_per_launch=alg_bytes, decisions_per_launch=f_per_launch,
@@ -568,22 +720,23 @@ def main():
         survey_bytes = N * f_per_launch * (192 + 4 + 29 + 4 * 4.07)
         roof["frac_survey_8d"] = survey_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS
         roof["frac_survey_8d_formula"] = "SURVEY.md 8(d): (192 + 4 + 29 + 4 x points walked) B per step = 241.3 B, state traffic charged per step"
-        t = _load_traffic("env_random", env_kernel, N, int(round(f_per_launch)))
+        t = _load_traffic("env_random", self.env_kernel, N, int(round(f_per_launch)))
         if t:
             roof["traffic"] = t["bytes_per_launch"]
             roof["traffic_source"] = t.get("source")
-        b = _load_binding(env_kernel, N, int(round(f_per_launch)))
+        b = _load_binding(self.env_kernel, N, int(round(f_per_launch)))
         if b:
             roof["binding"] = b
         return roof
 
-    def mpc_roofline(launch_s):
+    def mpc_roofline(self, launch_s):
         # K3 is fp64-VALU-bound.  Executed work with prefix sharing: 7 776 leaves x
         # 9 flop + 1 554 inner nodes x 13 flop = 90.2 kflop per lane decision (82.4 with the x1.0
         # weight dropped; the reference's
         # from-scratch formulation is 99 flop x 7 776 combos = 770 kflop).  No FMA may
         # be used (-ffp-contract=off is the parity contract), so 50 % of the FMA peak is the ceiling.
         # (variance_weight is exactly 1.0 here, so the kernel drops that multiplication: 8 per leaf)
+        N = self.N
         flops = N * (7776 * 8.0 - 1296 * 2.0 + 1554 * 13.0)   # 1 296 leaves repeat their parent digit: variance term is +0.0, skipped
         roof = dict(bound="valu_fp64", kernel="mpc_select_kernel<5,6>",
                     achieved=flops / launch_s / 1e12, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
@@ -598,188 +751,274 @@ def main():
             roof["traffic_source"] = t.get("source")
         return roof
 
-    roof = env_roofline() if a.workload == "env_random" else mpc_roofline(avg_launch_s)
+    # ---- block: self-check (N = 1).  Part 1 keeps what the LAST TIMED launch wrote for a sample of lanes -- its observation
+    #      rows, rewards and done bytes -- before anything overwrites the slab; part 2 replays those lanes through the oracle ----
+    def selfcheck_capture(self):
+        torch, N = self.torch, self.N
+        info = getattr(self.run, "info", None)
+        if not (info and info["last"]):
+            return None
+        b_, f_, n0_ = info["last"]
+        rng_ = np.random.default_rng(5)
+        pick = np.unique(np.concatenate([np.arange(8), np.arange(N - 8, N), [63, 64, 127, 128],
+                                         rng_.integers(0, N, 300)])).astype(np.int64)
+        pick = pick[(pick >= 0) & (pick < N)]
+        pk = torch.from_numpy(pick).to(self.dev)
+        bo = info["bufs"][b_]
+        return dict(pick=pick, n0=n0_, f=f_, obs=bo["obs"][:f_].index_select(2, pk).cpu().numpy(),
+                    reward=bo["reward"][:f_].index_select(1, pk).cpu().numpy(),
+                    done=bo["done"][:f_].index_select(1, pk).cpu().numpy())
 
-    # ---- N > 1 only: what the collective costs and what the launch shape costs, measured in the same process
+    # ---- block: sustained (N = 1): at least a second of back-to-back launches of the SAME shape in ONE bracket, so that
+    #      clocks and thermals have settled and an outside sampler sees the GPU busy; the headline stays what it was ----
+    def sustained(self):
+        torch, a, N, F = self.torch, self.a, self.N, self.F
+        info = self.run.info
+        n_l = int(np.ceil(a.sustained_seconds * 1.1 / max(self.avg_launch_s, 1e-6)))
+        per_mark = max(1, int(0.1 / max(self.avg_launch_s, 1e-6)))          # an event every ~100 ms
+        bufs_ = info["bufs"]
+        marks = []
+        self.barrier()
+        t0 = time.perf_counter()
+        for j in range(n_l):
+            if j % per_mark == 0:
+                e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((j, e))
+            self.env.step_random(F, a.seed, out=bufs_[j & 1])
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((n_l, e))
+        self.barrier()
+        el_s = time.perf_counter() - t0
+        info["n_done"] += n_l * F; info["last"] = None
+        win = [(j1 - j0) * F * N / (e0.elapsed_time(e1) * 1e-3) for (j0, e0), (j1, e1) in zip(marks[:-1], marks[1:])
+               if j1 - j0 == per_mark]
+        return {"value": N * F * n_l / el_s, "unit": self.unit, "seconds": el_s, "launches": n_l, "fuse": F,
+                "ms_per_step": el_s / (n_l * F) * 1e3,
+                "first_100ms_value": win[0] if win else None, "last_100ms_value": win[-1] if win else None,
+                "last_over_first": (win[-1] / win[0]) if len(win) >= 2 else None,
+                "windows_100ms": len(win), "min_window_value": min(win) if win else None,
+                "note": "one bracket (barrier + synchronize on both sides) around all launches; the windows are HIP "
+                        "events recorded every ~100 ms inside it"}
+
+    # ---- block: the reset()/get_video_chunk(quality) surface itself (N = 1): ONE decision per launch with the caller's
+    #      actions, abr_env_step (Simulator.py:155's call site turned inside out) ----
+    def single_step(self):
+        torch, N = self.torch, self.N
+        acts1 = torch.randint(0, len(LADDER), (N,), dtype=torch.int32, device=self.dev)
+        for _ in range(50):
+            self.env.step(acts1)
+        n1 = 400
+        self.barrier(); t0 = time.perf_counter()
+        for _ in range(n1):
+            self.env.step(acts1)
+        self.barrier()
+        el1 = time.perf_counter() - t0
+        return {"metric": "env_steps_per_sec_single_decision_launches", "value": N * n1 / el1, "unit": "env-steps/s",
+                "launches": n1, "us_per_launch": el1 / n1 * 1e6, "impl": self.env.effective_impl(fused=False),
+                "call": "abr_env_step(actions): one decision per launch, caller-supplied actions (a fixed random vector)"}
+
+    # ---- block (N > 1 only): what the collective costs and what the launch shape costs, measured in the same process
     #      with the same bracket, so that the scaling curve can be read: (1) the SAME launches without the
     #      all-gather; (2) the N = 1 launch shape (one launch of F1 decisions) without the all-gather ----
-    def control_block(env_, N_, F_used, total_lanes_):
+    def control_block(self, env_, N_, F_used, total_lanes_, total_arg=None):
         out = {}
-        for name, f_ in (("same_launches_no_gather", F_used), ("n1_launch_shape_no_gather", F1)):
+        for name, f_ in (("same_launches_no_gather", F_used), ("n1_launch_shape_no_gather", self.F1)):
             evc = []
-            runc, _ = make_random_runner(env_, N_, f_, evc, False, gather_on=False)
-            runc(min(W, 2 * f_), False)
-            reps = max(1, min(repeats, 12))
-            tc = float(np.median([timed_region(runc, K) for _ in range(reps)]))
-            lsc, _ = launch_stats(evc)
-            out[name] = {"value": total_lanes_ * K / tc, "ms_per_step": tc / K * 1e3, "fuse": f_,
-                         "launches_per_region": -(-K // f_), "avg_launch_us": lsc * 1e6, "repeats": reps}
+            runc, _ = self.make_random_runner(env_, N_, f_, evc, False, gather_on=False, total_lanes=total_arg)
+            runc(min(self.W, 2 * f_), False)
+            reps = max(1, min(self.repeats, 12))
+            tc = float(np.median([self.timed_region(runc, self.K) for _ in range(reps)]))
+            lsc, _ = self.launch_stats(evc)
+            out[name] = {"value": total_lanes_ * self.K / tc, "ms_per_step": tc / self.K * 1e3, "fuse": f_,
+                         "launches_per_region": -(-self.K // f_), "avg_launch_us": lsc * 1e6, "repeats": reps}
         return out
 
-    control = None
-    if a.workload == "env_random" and (world > 1 or force_dist) and not a.no_gather:
-        control = control_block(env, N, F, N * world)
-
-    # ---- the other half of BASELINE.json's metric, same process, same JSON line ----
-    secondary = None
-    if a.workload == "env_random" and world == 1 and not a.no_secondary:
+    # ---- block: the other half of BASELINE.json's metric, same process, same JSON line ----
+    def secondary(self):
+        N = self.N
         ev2 = []
-        player, ctl, hn0, hs0 = mpc_setup()
-        run2 = mpc_runner(player, ctl, hn0, hs0, ev2, False)
+        _, ctl = self.mpc_setup()
+        run2 = self.mpc_runner(ctl, ev2, False)
         K2, W2 = 100, 100
         run2(W2, False)
         # five regions of K2 selects, the median reported and all five kept: the first region after the env
         # workload runs on a clock that is still settling (a 100-select region is 20 ms)
-        times2 = [timed_region(run2, K2) for _ in range(5)]
+        times2 = [self.timed_region(run2, K2) for _ in range(5)]
         el2 = float(np.median(times2))
-        ls2, _ = launch_stats(ev2)
-        secondary = {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
-                     "steps": K2, "warmup": W2, "ms_per_step": el2 / K2 * 1e3,
-                     "repeats": len(times2), "repeat_seconds": times2,
-                     "config": {"workload": "mpc", "lanes_per_gpu": N, "n_rates": 6, "horizon": 5,
-                                "combos_per_lane": 6 ** 5, "predictor": "harmonic",
-                                # every select grows the lanes' history by `horizon` predictions (D9), as repeated
-                                # next_bitrate() calls do in the reference; round 2's loop restored it between selects
-                                "history_restore": False},
-                     "roofline": mpc_roofline(ls2)}
+        ls2, _ = self.launch_stats(ev2)
+        return {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
+                "steps": K2, "warmup": W2, "ms_per_step": el2 / K2 * 1e3,
+                "repeats": len(times2), "repeat_seconds": times2,
+                "config": {"workload": "mpc", "lanes_per_gpu": N, "n_rates": 6, "horizon": 5,
+                           "combos_per_lane": 6 ** 5, "predictor": "harmonic",
+                           # every select grows the lanes' history by `horizon` predictions (D9), as repeated
+                           # next_bitrate() calls do in the reference; round 2's loop restored it between selects
+                           "history_restore": False},
+                "roofline": self.mpc_roofline(ls2)}
 
-    # ---- BASELINE.json configs[3] / north_star "1/2/4/8-GPU scaling curve on 1 048 576 lanes": the SAME job
+    # ---- block: BASELINE.json configs[3] / north_star "1/2/4/8-GPU scaling curve on 1 048 576 lanes": the SAME job
     #      split over however many ranks this run has, measured in this process after the headline metric
     #      (which stays 65 536 lanes per GPU so that N = 1 is BENCH's number).  The driver's back-to-back
     #      N = 1, 2, 4, 8 runs therefore yield both curves: `value` (weak) and `strong_1048576.value`. ----
-    strong = None
-    if a.workload == "env_random" and not a.total_lanes and not a.no_strong and STRONG_TOTAL % world == 0:
-        lane0s, Ns = shard_range(STRONG_TOTAL, world, rank)
-        tids, offs = lane_assignment(lane0s, Ns, traces)
-        env_s = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, traces), Ns, device=dev,
+    def strong(self):
+        torch, A, a, F, K = self.torch, self.A, self.a, self.F, self.K
+        lane0s, Ns = self.shard_range(STRONG_TOTAL, self.world, self.rank)
+        tids, offs = lane_assignment(lane0s, Ns, self.traces)
+        env_s = A.BatchedABREnv(self.mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, self.traces), Ns, device=self.dev,
                                 auto_reset=True, lane_id_base=lane0s, impl=a.impl)
         env_s.reset(torch.from_numpy(tids), torch.from_numpy(offs))
         ev_s = []
-        run_s, gat_s = make_random_runner(env_s, Ns, F, ev_s, False)
-        run_s(min(W, 2 * F), False)
-        reps_s = max(1, min(repeats, 12))
-        times_s = [timed_region(run_s, K) for _ in range(reps_s)]
+        run_s, gat_s = self.make_random_runner(env_s, Ns, F, ev_s, False, total_lanes=STRONG_TOTAL)
+        run_s(min(self.W, 2 * F), False)
+        reps_s = max(1, min(self.repeats, 12))
+        times_s = [self.timed_region(run_s, K) for _ in range(reps_s)]
         el_s = float(np.median(times_s))
-        ls_s, _ = launch_stats(ev_s)
+        ls_s, _ = self.launch_stats(ev_s)
         control_s = None
-        if (world > 1 or force_dist) and not a.no_gather:
-            control_s = control_block(env_s, Ns, F, STRONG_TOTAL)
-        strong = {"metric": "env_steps_per_sec", "value": STRONG_TOTAL * K / el_s, "unit": "env-steps/s",
-                  "scaling": "strong", "n_gpus": world, "total_lanes": STRONG_TOTAL, "lanes_per_gpu": Ns,
-                  "steps": K, "ms_per_step": el_s / K * 1e3, "repeats": reps_s, "fuse": F,
-                  "launches_per_region": -(-K // F), "control": control_s,
-                  "impl": env_s.effective_impl(fused=F > 1), "avg_launch_us": ls_s * 1e6,
-                  "collective": (f"1 all_gather_into_tensor per launch, {(8 + F) * Ns * 4} B per rank; issued "
-                                 f"{gat_s.n_collectives}x" if gat_s else "none")}
+        if self.distributed and not a.no_gather:
+            control_s = self.control_block(env_s, Ns, F, STRONG_TOTAL, total_arg=STRONG_TOTAL)
+        n_max = max(self.shard_range(STRONG_TOTAL, self.world, r)[1] for r in range(self.world))
+        out = {"metric": "env_steps_per_sec", "value": STRONG_TOTAL * K / el_s, "unit": "env-steps/s",
+               "scaling": "strong", "n_gpus": self.world, "total_lanes": STRONG_TOTAL, "lanes_per_gpu": Ns,
+               "steps": K, "ms_per_step": el_s / K * 1e3, "repeats": reps_s, "fuse": F,
+               "launches_per_region": -(-K // F), "control": control_s,
+               "impl": env_s.effective_impl(fused=F > 1), "avg_launch_us": ls_s * 1e6,
+               "collective": (f"1 all_gather_into_tensor per launch, {(8 + F) * n_max * 4} B per rank; issued "
+                              f"{gat_s.n_collectives}x" if gat_s else "none")}
         del env_s
+        return out
 
-    # ---- the MPC-driven rollout (N = 1): BASELINE.json configs[2] composed (65 536 envs x MPC horizon 5, abr_env_step_mpc)
-    #      and configs[4]'s per-rank shape (131 072 lanes of the 1 048 576-lane job, rank 7's lane ids, mixed 300-3 000-point
-    #      traces).  One timed region = ONE 48-decision episode of every lane in one abr_env_step_mpc call; the K3 / K1
-    #      split comes from HIP events around the two halves of a host-loop pass over the same decisions. ----
-    mpc_rollout = None
-    if a.workload == "env_random" and world == 1 and not a.no_mpc_rollout:
-        mpc_rollout = {}
+    # ---- block: the MPC-driven rollout (N = 1): BASELINE.json configs[2] composed (65 536 envs x MPC horizon 5,
+    #      abr_env_step_mpc) and configs[4]'s per-rank shape (131 072 lanes of the 1 048 576-lane job, rank 7's lane ids, mixed
+    #      300-3 000-point traces).  One timed region = ONE 48-decision episode of every lane in one abr_env_step_mpc call; the
+    #      K3 / K1 split comes from HIP events around the two halves of a host-loop pass over the same decisions. ----
+    def mpc_rollout(self):
+        torch, A, a, dev, OBS_DIM = self.torch, self.A, self.a, self.dev, self.OBS_DIM
+        out = {}
         for name, lanes_r, mixed_r, base_r in (("configs2_65536", 65536, False, 0),
                                                ("configs4_rank7_131072_mixed", 131072, True, 7 * 131072)):
-            tr_r = synth_traces(mixed_r)
-            tid_r, off_r = lane_assignment(base_r, lanes_r, tr_r)
-            env_r = A.BatchedABREnv(mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, tr_r), lanes_r, device=dev,
-                                    auto_reset=True, lane_id_base=base_r, impl=a.impl)
-            env_r.reset(torch.from_numpy(tid_r), torch.from_numpy(off_r))
-            ctl_r = A.BatchedMPCController(
-                A.EnvPlayer(env_r, mpd=A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
-                            qoe=A.QOEMetric(4.3, 1.0, 0.0)), horizon=5, clip_horizon=True, device=dev)
-            out_r = dict(obs=torch.empty(V, OBS_DIM, lanes_r, dtype=torch.float32, device=dev),
-                         reward=torch.empty(V, lanes_r, dtype=torch.float32, device=dev),
-                         done=torch.empty(V, lanes_r, dtype=torch.uint8, device=dev),
-                         actions=torch.empty(V, lanes_r, dtype=torch.int32, device=dev))
-
-            def region(n_, _e=env_r, _c=ctl_r, _o=out_r):
-                _e.step_mpc(_c, n_, out=_o)
-            region(V)                                            # one episode of warm-up
-            times_r = []
-            for _ in range(5):
-                barrier(); t0 = time.perf_counter(); region(V); barrier()
-                times_r.append(time.perf_counter() - t0)
-            el_r = float(np.median(times_r))
-            ends = int(out_r["done"][-1].sum().item())           # every lane ends its episode at the last decision
-            # the split: the same decisions as select + step from the host, HIP events around each half
-            evs = []
-            for _ in range(V):
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e2 = torch.cuda.Event(enable_timing=True)
-                e0.record(); act = ctl_r.next_bitrate(); e1.record()
-                env_r.step(torch.clamp(act, min=0))      # D13 at chunk 0: "no decision" -> rate 0, as the fused call does
-                e2.record()
-                evs.append((e0, e1, e2))
-            torch.cuda.synchronize(dev)
-            k3 = float(np.median([x.elapsed_time(y) for x, y, _ in evs])) * 1e3
-            k1 = float(np.median([y.elapsed_time(z) for _, y, z in evs])) * 1e3
-            mpc_rollout[name] = {
-                "metric": "env_steps_per_sec_mpc_policy", "value": lanes_r * V / el_r, "unit": "env-steps/s",
-                "combos_per_sec": lanes_r * V * 6 ** 5 / el_r, "lanes": lanes_r, "lane_id_base": base_r,
-                "decisions_per_region": V, "us_per_decision": el_r / V * 1e6, "repeats": len(times_r), "repeat_seconds": times_r,
-                "traces": f"{N_TRACES} x " + ("300..3000" if mixed_r else str(TRACE_LEN)),
-                "episodes_ended_at_last_decision": ends, "call": "abr_env_step_mpc(n_steps=48): K3 + K1 per decision, no host work between",
-                "split_host_loop": {"k3_select_us": k3, "k1_step_us": k1, "k1_impl": env_r.effective_impl(fused=False),
-                                    "note": "medians of HIP events around next_bitrate() and step() (+ one clamp kernel) of a host "
-                                            "loop over one more episode"}}
-            del env_r, ctl_r, out_r
+            try:
+                out[name] = self._mpc_rollout_one(lanes_r, mixed_r, base_r)
+            except Exception as e:                          # noqa: BLE001 -- the other shape still counts
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+        return out
 
-    cpu = None
-    selfcheck = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        if selfcheck_in is not None:
-            selfcheck = selfcheck_env(selfcheck_in, traces, lane0, a.seed)
-        cpu = cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(traces, a.seed)
-        if secondary is not None:
-            secondary["cpu_baseline"] = cpu_baseline_mpc(budget_s=5.0)
+    def _mpc_rollout_one(self, lanes_r, mixed_r, base_r):
+        torch, A, a, dev, OBS_DIM = self.torch, self.A, self.a, self.dev, self.OBS_DIM
+        tr_r = synth_traces(mixed_r)
+        tid_r, off_r = lane_assignment(base_r, lanes_r, tr_r)
+        env_r = A.BatchedABREnv(self.mpd, A.QOEMetric(*WEIGHTS), A.NetworkInfo(INTERVAL, tr_r), lanes_r, device=dev,
+                                auto_reset=True, lane_id_base=base_r, impl=a.impl)
+        env_r.reset(torch.from_numpy(tid_r), torch.from_numpy(off_r))
+        ctl_r = A.BatchedMPCController(
+            A.EnvPlayer(env_r, mpd=A.MPD(V, L, MAX_BUFFER, START_UP, [A.Chunk(LADDER, [b * L for b in LADDER])] * V),
+                        qoe=A.QOEMetric(4.3, 1.0, 0.0)), horizon=5, clip_horizon=True, device=dev)
+        out_r = dict(obs=torch.empty(V, OBS_DIM, lanes_r, dtype=torch.float32, device=dev),
+                     reward=torch.empty(V, lanes_r, dtype=torch.float32, device=dev),
+                     done=torch.empty(V, lanes_r, dtype=torch.uint8, device=dev),
+                     actions=torch.empty(V, lanes_r, dtype=torch.int32, device=dev))
 
-    if rank == 0:
-        total_units = units_per_step * K
-        gathering = (world > 1 or force_dist) and not a.no_gather and a.workload == "env_random"
-        line = {
-            "metric": metric, "value": total_units / elapsed, "unit": unit, "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "strong" if a.total_lanes else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "repeats": repeats, "repeat_seconds": times,
-            "config": {"workload": a.workload, "lanes_per_gpu": N, "total_lanes": N * world,
-                       "fuse": F, "launches_per_region": -(-K // F), "fuse_at_n1": F1 if a.workload == "env_random" else 1,
-                       "impl": impl,
-                       "history_restore": False if a.workload != "env_random" else None,
-                       "video_length": V, "chunk_length_s": L, "n_rates": len(LADDER),
-                       "traces": f"{N_TRACES} x " + ("300..3000" if a.mixed_traces else str(TRACE_LEN)),
-                       "policy": "random(philox)" if a.workload == "env_random" else "mpc_h5",
-                       "hip_graph": bool(a.graph and world == 1 and a.workload == "env_random"),
-                       "auto_reset": True,
-                       "collective": (f"1 all_gather_into_tensor per launch of the packed slab [final obs 8xN | "
-                                      f"rewards {F}xN] float32 = {(8 + F) * N * 4} B per rank, overlapped "
-                                      f"with the next launch; backend {backend}; issued "
-                                      f"{gat.n_collectives if gat else 0}x" if gathering else "none")},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        if selfcheck is not None:
-            line["selfcheck"] = selfcheck
-        if sustained is not None:
-            line["sustained"] = sustained
-        if single_step is not None:
-            line["single_step"] = single_step
-        if mpc_rollout is not None:
-            line["mpc_rollout"] = mpc_rollout
-        if control is not None:
-            line["control"] = control
-        if secondary is not None:
-            line["secondary"] = secondary
-        if strong is not None:
-            line["strong_1048576"] = strong
-        print(json.dumps(line))
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
-    if rank == 0 and selfcheck is not None and selfcheck["mismatches"]:
-        raise SystemExit(f"bench.py self-check FAILED: {selfcheck['mismatches']} of {selfcheck['elements']} elements of the timed "
-                         f"launch differ from the oracle; first: {selfcheck['first_mismatch']}")
+        def region(n_):
+            env_r.step_mpc(ctl_r, n_, out=out_r)
+        region(V)                                            # one episode of warm-up
+        times_r = []
+        for _ in range(5):
+            self.barrier(); t0 = time.perf_counter(); region(V); self.barrier()
+            times_r.append(time.perf_counter() - t0)
+        el_r = float(np.median(times_r))
+        ends = int(out_r["done"][-1].sum().item())           # every lane ends its episode at the last decision
+        # the split: the same decisions as select + step from the host, HIP events around each half
+        evs = []
+        for _ in range(V):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e2 = torch.cuda.Event(enable_timing=True)
+            e0.record(); act = ctl_r.next_bitrate(); e1.record()
+            env_r.step(torch.clamp(act, min=0))      # D13 at chunk 0: "no decision" -> rate 0, as the fused call does
+            e2.record()
+            evs.append((e0, e1, e2))
+        torch.cuda.synchronize(dev)
+        k3 = float(np.median([x.elapsed_time(y) for x, y, _ in evs])) * 1e3
+        k1 = float(np.median([y.elapsed_time(z) for _, y, z in evs])) * 1e3
+        return {
+            "metric": "env_steps_per_sec_mpc_policy", "value": lanes_r * V / el_r, "unit": "env-steps/s",
+            "combos_per_sec": lanes_r * V * 6 ** 5 / el_r, "lanes": lanes_r, "lane_id_base": base_r,
+            "decisions_per_region": V, "us_per_decision": el_r / V * 1e6, "repeats": len(times_r), "repeat_seconds": times_r,
+            "traces": f"{N_TRACES} x " + ("300..3000" if mixed_r else str(TRACE_LEN)),
+            "episodes_ended_at_last_decision": ends, "call": "abr_env_step_mpc(n_steps=48): K3 + K1 per decision, no host work between",
+            "split_host_loop": {"k3_select_us": k3, "k1_step_us": k1, "k1_impl": env_r.effective_impl(fused=False),
+                                "note": "medians of HIP events around next_bitrate() and step() (+ one clamp kernel) of a host "
+                                        "loop over one more episode"}}
+
+    # ---- the whole run ----
+    def main(self):
+        a, em, wd = self.a, self.em, self.wd
+        with wd.phase("setup", max(a.phase_timeout, 300.0)):     # the first import of torch on a fresh box pages in for minutes
+            self.setup()
+        self.headline()
+        env_rand, n1 = a.workload == "env_random", self.world == 1
+        # N = 1: the self-check and the CPU baseline belong to the FIRST line printed, so that it is complete by itself
+        selfcheck = None
+        if self.rank == 0 and n1 and not a.no_cpu_baseline:
+            sc_in = None
+            if env_rand:
+                try:
+                    with wd.phase("selfcheck_capture"):
+                        sc_in = self.selfcheck_capture()
+                except Exception as e:                      # noqa: BLE001
+                    em.update(selfcheck={"error": f"{type(e).__name__}: {e}"})
+            if sc_in is not None:
+                try:
+                    with wd.phase("selfcheck", 300.0):
+                        selfcheck = selfcheck_env(sc_in, self.traces, self.lane0, a.seed)
+                    em.update(selfcheck=selfcheck)
+                except Exception as e:                      # noqa: BLE001
+                    em.update(selfcheck={"error": f"{type(e).__name__}: {e}"})
+            try:
+                with wd.phase("cpu_baseline", 300.0):
+                    em.update(cpu_baseline=cpu_baseline_mpc() if a.workload == "mpc" else cpu_baseline_env(self.traces, a.seed))
+            except Exception as e:                          # noqa: BLE001
+                em.update(cpu_baseline={"error": f"{type(e).__name__}: {e}"})
+        em.emit()                                           # the headline line: on stdout from here on, whatever comes next
+        if selfcheck is not None and selfcheck.get("mismatches"):
+            self.finish()
+            raise SystemExit(f"bench.py self-check FAILED: {selfcheck['mismatches']} of {selfcheck['elements']} elements of the "
+                             f"timed launch differ from the oracle; first: {selfcheck['first_mismatch']}")
+        fatal = self.world > 1
+        if env_rand and n1 and not a.no_sustained and getattr(self.run, "info", None):
+            guarded(em, wd, "sustained", self.sustained)
+        if env_rand and n1 and not a.no_single_step:
+            guarded(em, wd, "single_step", self.single_step)
+        if env_rand and self.distributed and not a.no_gather:
+            guarded(em, wd, "control", lambda: self.control_block(self.env, self.N, self.F, self.units_per_step,
+                                                                  total_arg=a.total_lanes or None), bound=2 * a.phase_timeout,
+                    fatal=fatal)
+        if env_rand and n1 and not a.no_secondary:
+            def sec():
+                s = self.secondary()
+                if self.rank == 0 and not a.no_cpu_baseline:
+                    try:
+                        s["cpu_baseline"] = cpu_baseline_mpc(budget_s=5.0)
+                    except Exception as e:                  # noqa: BLE001
+                        s["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                return s
+            guarded(em, wd, "secondary", sec, bound=2 * a.phase_timeout)
+        if env_rand and n1 and not a.no_mpc_rollout:
+            guarded(em, wd, "mpc_rollout", self.mpc_rollout, bound=2 * a.phase_timeout)
+        if env_rand and not a.total_lanes and not a.no_strong and STRONG_TOTAL % self.world == 0:
+            guarded(em, wd, "strong_1048576", self.strong, bound=3 * a.phase_timeout, fatal=fatal)
+        self.finish()
+
+    def finish(self):
+        if self.distributed:
+            try:
+                with self.wd.phase("destroy_process_group", 30.0):
+                    self.dist.destroy_process_group()
+            except Exception:                               # noqa: BLE001
+                pass
+        self.wd.stop()
+
+
+def main(argv=None):
+    Run(parse_args(argv)).main()
 
 
 if __name__ == "__main__":

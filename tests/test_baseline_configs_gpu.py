@@ -530,7 +530,7 @@ def test_bench_default_line_carries_both_scaling_curves_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-           "--lanes-per-gpu", "4096", "--min-timed-steps", "40"]
+           "--lanes-per-gpu", "4096", "--min-timed-steps", "40", "--allow-overrides"]     # (ABR_BENCH_STRONG_TOTAL changes the workload)
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -548,3 +548,8 @@ def test_bench_default_line_carries_both_scaling_curves_two_ranks():
         assert a["fuse"] == 10 and a["launches_per_region"] == 2 and a["value"] > 0
         assert b["fuse"] == 20 and b["launches_per_region"] == 1 and b["value"] > 0
     assert st["launches_per_region"] == 2
+    # every override in force is on record in the line, and the one that changes the workload needed --allow-overrides
+    assert line["config"]["overrides"]["ABR_BENCH_STRONG_TOTAL"] == "16384" and "ABR_BENCH_BACKEND" in line["config"]["overrides"]
+    cmd2 = [c for c in cmd if c != "--allow-overrides"]
+    refused = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=300)
+    assert refused.returncode != 0 and "allow-overrides" in refused.stderr and not refused.stdout.strip()

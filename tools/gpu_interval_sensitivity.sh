@@ -3,7 +3,7 @@
 # interval ends, so the download wave runs fewer trips while the player's work per decision stays about the same.
 S="--no-cpu-baseline --no-secondary --no-strong --no-sustained --no-mpc-rollout --no-single-step --steps 1920 --warmup 192"
 for r in 1 2; do for I in 1.0 2.0 4.0 1000.0; do
-  ABR_BENCH_INTERVAL=$I timeout -k 10 120 python bench.py $S 2>/dev/null | python -c "
+  ABR_BENCH_INTERVAL=$I timeout -k 10 120 python bench.py --allow-overrides $S 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
