@@ -23,11 +23,12 @@ from oracle import oracle as O  # noqa: E402
 from test_lane_jump_cpu import _random_config  # noqa: E402
 from helpers import DIAG_IMPLS, diag_lib, oracle_rewards  # noqa: E402
 
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
-t0 = time.time()
-bad, lane_steps, feats = 0, 0, {}
-for seed in range(n_seeds):
+IMPLS_ALL = ["split3", "split", "jump", "async", "ring3"]    # async / ring3: the diagnostic build (rejected pipelines)
+FEATURES = ["plain", "lane_speeds", "schedule", "vbr", "schedule+vbr"]
+
+
+def run_seed(seed, N, impls=IMPLS_ALL):
+    """One random configuration against the oracle.  Returns (mismatching elements, lane-steps, case name, description)."""
     rng = np.random.default_rng(50_000 + seed)
     meta, (lo, hi) = _random_config(rng)
     V, B = meta["video_length"], len(meta["ladder"])
@@ -37,8 +38,8 @@ for seed in range(n_seeds):
     tid = rng.integers(0, n_traces, N).astype(np.int32)
     off = np.array([rng.integers(0, lens[t]) for t in tid], np.int32)
     actions = rng.integers(0, B, (N, V)).astype(np.int32)
-    feature = ["plain", "lane_speeds", "schedule", "vbr", "schedule+vbr"][seed % 5]
-    impl = ["split3", "split", "jump", "async", "ring3"][(seed // 5) % 5]    # async / ring3: the diagnostic build (rejected pipelines)
+    feature = FEATURES[seed % 5]
+    impl = impls[(seed // 5) % len(impls)]
     fused = (seed // 25) % 2 == 1 or impl in ("async", "ring3")    # one abr_env_step_script call instead of V abr_env_step calls
     speeds, br = None, None
     if "lane_speeds" in feature:
@@ -71,16 +72,30 @@ for seed in range(n_seeds):
     b += int((f["play_id"].astype(np.int32) != fin["play_id"]).sum())
     b += int((~np.isclose(env.episode_qoe().cpu().numpy(), fin["qoe"], rtol=1e-10, atol=1e-12)).sum())
     b += int((~np.isclose(f["average_latency"], fin["average_latency"], rtol=1e-9, atol=1e-12)).sum())
-    if b:
-        print("MISMATCH seed", seed, feature, impl, b, meta)
-    bad += b
-    lane_steps += N * V
-    key = feature + "/" + impl + ("/fused" if fused else "")
-    feats[key] = feats.get(key, 0) + 1
     env.close()
-print(json.dumps(dict(seeds=n_seeds, lanes_per_seed=N, lane_steps=lane_steps, mismatches=bad,
-                      cases=feats, seconds=round(time.time() - t0, 1),
-                      compared="previous_bandwidths float64 ==, every per-step reward == float32(oracle-derived), "
-                               "final global/rebuffer/start_up/play time, "
-                               "buffer_level, play_id ==, episode QoE 1e-10, average_latency 1e-9")))
-sys.exit(1 if bad else 0)
+    return b, N * V, feature + "/" + impl + ("/fused" if fused else ""), (seed, feature, impl, meta)
+
+
+COMPARED = ("previous_bandwidths float64 ==, every per-step reward == float32(oracle-derived), final global/rebuffer/start_up/play "
+            "time, buffer_level, play_id ==, episode QoE 1e-10, average_latency 1e-9")
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    t0 = time.time()
+    bad, lane_steps, feats = 0, 0, {}
+    for seed in range(n_seeds):
+        b, ls, key, what = run_seed(seed, N)
+        if b:
+            print("MISMATCH seed", *what[:3], b, what[3])
+        bad += b
+        lane_steps += ls
+        feats[key] = feats.get(key, 0) + 1
+    print(json.dumps(dict(seeds=n_seeds, lanes_per_seed=N, lane_steps=lane_steps, mismatches=bad,
+                          cases=feats, seconds=round(time.time() - t0, 1), compared=COMPARED)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
