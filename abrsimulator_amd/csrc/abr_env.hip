@@ -1716,11 +1716,12 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
         int prev_r = prev_s[li];
         int32_t flat = 0;
         bool ok = true, is_leaf = false;
-        // digits of the prefix, most significant first
-        int digs[2];
-        if (D == 2) { digs[0] = pre / B; digs[1] = pre - digs[0] * B; } else { digs[0] = pre; digs[1] = 0; }
+        // digits of the prefix, most significant first (two scalars, not an array: indexed by the loop variable an array went
+        // to scratch -- the 12 B of private memory per lane of rounds 4-5, four scratch instructions per thread, here and not in
+        // the enumeration)
+        const int dig0 = (D == 2) ? pre / B : pre, dig1 = (D == 2) ? pre - dig0 * B : 0;
         for (int lvl = 0; lvl < D && ok && !is_leaf; lvl++) {
-            const int r = digs[lvl];
+            const int r = lvl == 0 ? dig0 : dig1;
             const double *brv = t.brv + lvl * B;
             const double b = brv[r];
             const double bp = brv[prev_r];
@@ -1728,7 +1729,7 @@ void mpc_select_kernel(MpcParams p, int T, int D, int LPB) {
             flat = flat * B + r;
             if (lvl == t.heff - 1) {
                 // clipped horizon ends inside the prefix: only all-zero remainders are real combos
-                for (int l2 = lvl + 1; l2 < D; l2++) if (digs[l2] != 0) ok = false;
+                if (lvl == 0 && D == 2 && dig1 != 0) ok = false;
                 is_leaf = true;
             } else {
                 const double tmp = pymax0(buf - t.tdl[lvl * B + r]);
