@@ -520,17 +520,34 @@ class Run:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
-    def timed_region(self, runner, n_steps):
-        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks."""
+    def timed_region(self, runner, n_steps, events=True):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks.  events: every launch of the
+        region between two HIP events (the kernel's own duration; costs a single-launch region ~7 us); False: launches only."""
         torch, dist = self.torch, self.dist
         self.barrier()
         t0 = time.perf_counter()
-        runner(n_steps, True)
+        runner(n_steps, "events" if events else "plain")
         self.barrier()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
         if self.distributed:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
+
+    def measure(self, runner, n_steps, reps, phase=None):
+        """`reps` x (one region with HIP events around every launch, one region with the launches only), interleaved, each
+        bracketed as timed_region() says.  Returns (times of the plain regions, times of the instrumented ones): the plain
+        ones are what a value is computed from, the instrumented ones fill the runner's event list (launch_stats)."""
+        plain, inst = [], []
+        for r in range(reps):
+            if phase:
+                with self.wd.phase(f"{phase}_with_events[{r}]"):
+                    inst.append(self.timed_region(runner, n_steps, events=True))
+                with self.wd.phase(f"{phase}[{r}]"):
+                    plain.append(self.timed_region(runner, n_steps, events=False))
+            else:
+                inst.append(self.timed_region(runner, n_steps, events=True))
+                plain.append(self.timed_region(runner, n_steps, events=False))
+        return plain, inst
 
     @staticmethod
     def launch_stats(events):
@@ -553,18 +570,23 @@ class Run:
                        reward=torch.empty(1, N, dtype=torch.float32, device=dev),
                        done=torch.empty(1, N, dtype=torch.uint8, device=dev), actions=None)
 
+        pool = []
+
         def run(n_steps, timed):
+            if not timed:                                 # warm-up call: HIP events are created on their first record()
+                while len(pool) < 2 * n_steps + 64:
+                    e = torch.cuda.Event(enable_timing=True); e.record(); pool.append(e)
             for _ in range(n_steps):
                 # (no history restore between selects: every call grows the lanes' throughput history by
                 # `horizon` predictions, D9, exactly as repeated next_bitrate() calls do in the reference)
-                if timed:
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                if timed == "events":
+                    e0 = pool.pop() if pool else torch.cuda.Event(enable_timing=True); e0.record()
                 if drive_env:
                     self.env.step_mpc(ctl, 1, out=mpc_out)       # K3 + K1 on the device, no host glue
                 else:
                     ctl.next_bitrate()
-                if timed:
-                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                if timed == "events":
+                    e1 = pool.pop() if pool else torch.cuda.Event(enable_timing=True); e1.record()
                     events.append((e0, e1, 1))
         return run
 
@@ -603,26 +625,29 @@ class Run:
             return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
 
         def run_(n_steps, timed):
+            """timed: False = warm-up; "events" = a region whose every launch sits between two HIP events (the kernel's
+            duration); True / "plain" = a region with nothing but the launches in it (the headline)."""
             left = n_steps
+            ev_on = timed == "events"
             if not timed:                                 # warm-up call: stock the pool for the timed calls
                 need = 2 * (max(1, -(-a.min_timed_steps // max(K, 1))) + 1) * (K // F_ + 2)
                 while len(pool) < need:
                     e = torch.cuda.Event(enable_timing=True); e.record(); pool.append(e)
             while graph is not None and left >= F_:
-                if timed:
+                if ev_on:
                     e0 = take(); e0.record()
                 graph.replay()
-                if timed:
+                if ev_on:
                     e1 = take(); e1.record()
                     events_.append((e0, e1, F_))
                 info["last"] = (0, F_, info["n_done"]); info["n_done"] += F_
                 left -= F_
             while left > 0:
                 f = min(F_, left)
-                evp = (take(), take()) if timed else None
+                evp = (take(), take()) if ev_on else None
                 b = sh._it & 1
                 sh.step_random(f, a.seed, events=evp)     # wait for the slab, launch, enqueue the all-gather
-                if timed:
+                if ev_on:
                     events_.append((evp[0], evp[1], f))
                 info["last"] = (b, f, info["n_done"]) if f == F_ else None
                 info["n_done"] += f
@@ -667,10 +692,11 @@ class Run:
                 self.unit, self.metric = "env-steps/s", "env_steps_per_sec_mpc_policy"
         with self.wd.phase("warmup"):
             self.run(W, False)
-        self.times = []
-        for r in range(self.repeats):
-            with self.wd.phase(f"timed_region[{r}]"):
-                self.times.append(self.timed_region(self.run, K))
+        # The headline's regions hold the K steps and NOTHING else.  The kernel's duration (roofline) is measured live, with HIP
+        # events around every launch, in regions of the same K steps and the same bracket INTERLEAVED with them: the two event
+        # records cost a region that is one launch ~7 us (5 % of the driver's 20-decision region, tools/gpu_event_cost.py), and
+        # that is instrumentation, not workload.  Both series are in the line (repeat_seconds, repeat_seconds_with_events).
+        self.times, self.times_ev = self.measure(self.run, K, self.repeats, phase="timed_region")
         self.elapsed = float(np.median(self.times))
         self.avg_launch_s, self.f_per_launch = self.launch_stats(self.ev)
         roof = self.env_roofline() if a.workload == "env_random" else self.mpc_roofline(self.avg_launch_s)
@@ -694,7 +720,9 @@ class Run:
         self.em.update(metric=self.metric, value=self.units_per_step * K / self.elapsed, unit=self.unit, n_gpus=self.world,
                        steps=K, warmup=W, ms_per_step=self.elapsed / K * 1e3, higher_is_better=True,
                        scaling="strong" if a.total_lanes else "weak", vs_baseline=None, dtype="f64", data="synthetic",
-                       repeats=self.repeats, repeat_seconds=self.times, config=config, roofline=roof, cpu_baseline=None)
+                       repeats=self.repeats, repeat_seconds=self.times, repeat_seconds_with_events=self.times_ev,
+                       value_with_events=self.units_per_step * K / float(np.median(self.times_ev)),
+                       config=config, roofline=roof, cpu_baseline=None)
 
     def env_roofline(self):
         # algorithmic bytes per launch (DESIGN.md "Roofline"): per lane, state in + out once per
@@ -825,7 +853,7 @@ class Run:
             runc, _ = self.make_random_runner(env_, N_, f_, evc, False, gather_on=False, total_lanes=total_arg)
             runc(min(self.W, 2 * f_), False)
             reps = max(1, min(self.repeats, 12))
-            tc = float(np.median([self.timed_region(runc, self.K) for _ in range(reps)]))
+            tc = float(np.median(self.measure(runc, self.K, reps)[0]))
             lsc, _ = self.launch_stats(evc)
             out[name] = {"value": total_lanes_ * self.K / tc, "ms_per_step": tc / self.K * 1e3, "fuse": f_,
                          "launches_per_region": -(-self.K // f_), "avg_launch_us": lsc * 1e6, "repeats": reps}
@@ -841,7 +869,7 @@ class Run:
         run2(W2, False)
         # five regions of K2 selects, the median reported and all five kept: the first region after the env
         # workload runs on a clock that is still settling (a 100-select region is 20 ms)
-        times2 = [self.timed_region(run2, K2) for _ in range(5)]
+        times2, _ = self.measure(run2, K2, 5)
         el2 = float(np.median(times2))
         ls2, _ = self.launch_stats(ev2)
         return {"metric": "mpc_combos_per_sec", "value": N * 6 ** 5 * K2 / el2, "unit": "combos/s",
@@ -869,7 +897,7 @@ class Run:
         run_s, gat_s = self.make_random_runner(env_s, Ns, F, ev_s, False, total_lanes=STRONG_TOTAL)
         run_s(min(self.W, 2 * F), False)
         reps_s = max(1, min(self.repeats, 12))
-        times_s = [self.timed_region(run_s, K) for _ in range(reps_s)]
+        times_s, _ = self.measure(run_s, K, reps_s)
         el_s = float(np.median(times_s))
         ls_s, _ = self.launch_stats(ev_s)
         control_s = None

@@ -483,7 +483,7 @@ def test_bench_two_ranks_one_collective_per_launch():
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total_lanes"] == 8192
         assert line["config"]["lanes_per_gpu"] == 4096 and line["config"]["fuse"] == fuse
-        launches = (steps + warm) // fuse
+        launches = (2 * steps + warm) // fuse      # the warm-up, one region with HIP events around the launches, one without
         assert line["config"]["collective"].startswith("1 all_gather_into_tensor per launch")
         assert line["config"]["collective"].endswith(f"issued {launches}x"), line["config"]["collective"]
         assert line["value"] > 0 and "secondary" not in line and line["cpu_baseline"] is None
@@ -502,12 +502,14 @@ def test_bench_rccl_code_path_with_one_rank():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "backend nccl" in line["config"]["collective"] and line["config"]["collective"].endswith("issued 3x")
+    assert "backend nccl" in line["config"]["collective"] and line["config"]["collective"].endswith("issued 5x")   # 1 warm-up launch + 2 regions x 2
     assert line["value"] > 0
     # the scaling-curve job (BASELINE.json configs[3]) rides in the same line: 1 048 576 lanes on this one rank
     st = line["strong_1048576"]
     assert st["total_lanes"] == 1048576 and st["lanes_per_gpu"] == 1048576 and st["scaling"] == "strong"
-    assert st["value"] > line["value"] and st["collective"].endswith("issued 3x")
+    assert st["value"] > line["value"] and st["collective"].endswith("issued 5x")
+    # the headline's regions carry no instrumentation; the regions with HIP events around every launch are reported beside them
+    assert len(line["repeat_seconds"]) == len(line["repeat_seconds_with_events"]) == line["repeats"] and line["value_with_events"] > 0
 
 
 def test_sharded_env_over_rccl_with_one_rank():
