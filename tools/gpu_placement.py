@@ -63,5 +63,11 @@ for rep in range(REPS):
         gl = np.array([life[g] for gs in good for g in gs])
         print(f"  workgroups on balanced CUs: lifetime mean {gl.mean():.0f} max {gl.max():.0f};  on the others: "
               f"mean {np.mean([life[g] for _, gs, _ in bad for g in gs]) if bad else 0:.0f} max {max([life[g] for _, gs, _ in bad for g in gs]) if bad else 0:.0f}")
+    if rep == REPS - 1 and os.environ.get("ABR_PLACEMENT_DUMP"):
+        import json
+        rt = (w[:, 9].astype(np.float64) - w[:, 8].astype(np.float64)) * 0.01      # microseconds (s_memrealtime, 100 MHz)
+        rt0 = (w[:, 8].astype(np.float64) - w[:, 8].astype(np.float64).min()) * 0.01
+        json.dump(dict(lanes=N, impl=IMPL, decisions=48, xcc=(hw[:, 0] >> 16).tolist(), cu=cu.tolist(), lifetime_cycles=life.tolist(),
+                       wall_us=rt.tolist(), begin_us=rt0.tolist()), open(os.environ["ABR_PLACEMENT_DUMP"], "w"))
     c0 = sorted(by_cu)[0]
     print("  a balanced CU for comparison:", [(g, simd[g].tolist(), slot[g].tolist(), int(life[g])) for g in by_cu[sorted(set(by_cu) - {b[0] for b in bad})[0]]])
