@@ -3,7 +3,7 @@
 the GPU box) into profiles/ (tracked): rocprofv3 kernel stats, PMC summaries, bench JSON lines.
 
   python tools/collect_profiles.py --stage DIR   on the GPU box: DIR/*/.../*.csv -> DIR/summary.json
-  python tools/collect_profiles.py               here: gpurun_out/<round>/ -> profiles/r03_*
+  python tools/collect_profiles.py               here: gpurun_out/<round>/ -> profiles/<round>_*      (round = ABR_ROUND_TAG, default r06)
 """
 import argparse
 import collections
@@ -14,7 +14,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("ABR_ROUND_TAG", "r05")
+TAG = os.environ.get("ABR_ROUND_TAG", "r06")
 ENV_KERNEL = "env_split3_kernel<2>"
 MPC_KERNEL = "mpc_select_kernel<5, 6, 1>"
 LANES, FUSE = 65536, 48
@@ -59,10 +59,20 @@ def collect():
     G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
     s = json.load(open(os.path.join(G, "summary.json")))
     for src in ("bench_default.json", "bench_driver_args.json", "bench_mpc.json", "bench_env_mpc.json", "bench_env_mpc_mixed.json",
-                "sweeps.txt", "role_stamps_split.txt", "role_stamps_split3.txt", "role_stamps_ring3.txt", "async_role_stats.txt",
-                "mpc_phase_stamps.txt", "mpc_sq_counters.txt", "gpu_fuzz.json"):
-        if os.path.exists(os.path.join(G, src)):
-            shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
+                "sweeps.txt", "sweep_impl.txt", "role_stamps_split.txt", "role_stamps_split3.txt", "role_stamps_split_131072.txt",
+                "role_stamps_ring3.txt", "async_role_stats.txt", "placement_split3.txt",
+                "mpc_phase_stamps.txt", "mpc_sq_counters.txt", "gpu_fuzz.json", "gpu_fuzz_extended.json"):
+        if not os.path.exists(os.path.join(G, src)):
+            continue
+        if src.startswith("bench_"):
+            # bench.py prints its line again after every block: the LAST line is the complete one, and it is what is kept
+            lines = [ln for ln in open(os.path.join(G, src)).read().splitlines() if ln.startswith("{")]
+            if lines:
+                open(os.path.join(P, f"{TAG}_{src}"), "w").write(lines[-1] + "\n")
+            continue
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{src}"))
+    if os.path.exists(os.path.join(G, "soak_extended.jsonl")):
+        shutil.copy(os.path.join(G, "soak_extended.jsonl"), os.path.join(P, f"{TAG}_soak_parity_extended.jsonl"))
     for name, dst in (("stats_env", "env_random_fuse48_kernel_stats.csv"), ("stats_env_f20", "env_random_fuse20_kernel_stats.csv"),
                       ("stats_mpc", "mpc_kernel_stats.csv"), ("stats_env_mpc", "env_mpc_kernel_stats.csv")):
         fs = sorted(glob.glob(os.path.join(G, name, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # (earlier runs of the round leave theirs behind)

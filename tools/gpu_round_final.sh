@@ -1,0 +1,97 @@
+# The round's measurement sweep on the GPU box (ONE script; earlier rounds' copies: tools/history/gpu_r0N_final.sh).
+#   part 1  tests, bench lines (default / driver arguments / MPC / MPC-driven rollout / configs[4] at full size), lane / fuse /
+#           implementation sweeps, role stamps
+#   part 2  rocprofv3 kernel stats, HBM traffic counters in SEPARATE --pmc passes, SQ counters -- for the default fuse 48 AND for
+#           the driver's `--steps 20` launches, so that the driver-run line finds its own traffic / binding
+#   part 3  parity soaks at scale + the device fuzz
+#   part 4  the longer fuzz / MPC / rollout soaks, and which implementation wins at which lane count
+# Everything lands under gpurun_out/$TAG/; `python tools/collect_profiles.py` (here, ABR_ROUND_TAG=$TAG) copies the summaries
+# into profiles/.        usage: gpurun -- bash tools/gpu_round_final.sh <part> [tag]
+set -e
+R=$GRAFT_REPO_ROOT
+TAG=${2:-r06}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+LEAN="--no-cpu-baseline --no-secondary --no-strong --no-sustained --no-mpc-rollout --no-single-step"
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'impl',d['config']['impl'],'fuse',d['config']['fuse'],'lanes',d['config']['lanes_per_gpu'],'value %.4g'%d['value'],'launch_us %.1f'%d['roofline']['avg_launch_us'],'frac %.4f'%d['roofline']['frac'])" | tee -a $O/$2; }
+if [ "$1" = "1" ]; then
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1 || { tail -30 $O/pytest.txt; exit 1; }
+tail -2 $O/pytest.txt
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench_default.err
+python bench.py --workload mpc --steps 100 --warmup 10 > $O/bench_mpc.json 2>> $O/bench_default.err
+python bench.py --workload env_mpc --steps 96 --warmup 8 --no-cpu-baseline > $O/bench_env_mpc.json 2>> $O/bench_default.err
+# BASELINE.json configs[4] at its FULL size on one GPU: 1 048 576 envs x MPC horizon 5, mixed 300-3 000-point traces
+python bench.py --workload env_mpc --lanes-per-gpu 1048576 --mixed-traces --steps 48 --warmup 48 --no-cpu-baseline > $O/bench_env_mpc_mixed.json 2>> $O/bench_default.err
+echo "bench lines done"
+rm -f $O/sweeps.txt
+for F in 1 16 20 48; do python bench.py --steps 960 --warmup 96 --fuse $F $LEAN 2>/dev/null | line fuse sweeps.txt; done
+for N in 16384 32768 81920 98304 131072 262144 1048576; do python bench.py --steps 480 --warmup 96 --lanes-per-gpu $N $LEAN 2>/dev/null | line lanes sweeps.txt; done
+python bench.py --mixed-traces --steps 960 --warmup 96 $LEAN 2>/dev/null | line mixed_traces_300_3000 sweeps.txt
+for I in split jump tick; do python bench.py --impl $I --steps 480 --warmup 96 $LEAN 2>/dev/null | line other_impl sweeps.txt; done
+make -C tools/diag/csrc -s ../lib/libabr_hip_diag.so ../lib/libabr_hip_stamps.so 2>/dev/null   # diagnostic builds (rejected pipelines, stamps)
+for I in ring3 async; do ABR_HIP_LIB=libabr_hip_diag.so python bench.py --impl $I --steps 480 --warmup 96 $LEAN 2>/dev/null | line diagnostic_build sweeps.txt; done
+echo "sweeps done"
+for I in split split3; do ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 65536 $I 2>&1 | grep -v amdgpu | grep -v " 0 cycles" > $O/role_stamps_$I.txt || true; done
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps.py 131072 split 2>&1 | grep -v amdgpu | grep -v " 0 cycles" > $O/role_stamps_split_131072.txt || true
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_placement.py 65536 split3 3 2>&1 | grep -v amdgpu > $O/placement_split3.txt || true
+ABR_HIP_LIB=libabr_hip_stamps.so python tools/gpu_stamps_mpc.py > $O/mpc_phase_stamps.txt 2>&1 || true
+tail -30 $O/role_stamps_split3.txt
+exit 0
+fi
+if [ "$1" = "3" ]; then
+S=$O/soak.jsonl; rm -f $S
+python tools/soak_parity.py 1048576 uniform split3 | tee -a $S
+python tools/soak_parity.py 1048576 uniform split | tee -a $S
+python tools/soak_parity.py 1048576 uniform auto | tee -a $S
+python tools/soak_parity.py 262144 mixed split3 | tee -a $S
+python tools/soak_parity.py 262144 mixed split | tee -a $S
+python tools/soak_parity.py 262144 mixed jump | tee -a $S
+python tools/soak_mpc.py 131072 | tee -a $S
+python tools/soak_rollout.py 8192 | tee -a $S
+python tools/gpu_fuzz.py 1250 512 | tee $O/gpu_fuzz.json
+exit 0
+fi
+if [ "$1" = "4" ]; then
+S=$O/soak_extended.jsonl; rm -f $S
+python tools/soak_mpc.py 524288 | tee -a $S
+python tools/soak_rollout.py 32768 | tee -a $S
+python tools/gpu_fuzz.py 6000 512 | tee $O/gpu_fuzz_extended.json
+rm -f $O/sweep_impl.txt
+for N in 81920 98304 114688 131072 163840 196608 262144; do for I in split jump; do python bench.py --impl $I --steps 480 --warmup 96 --lanes-per-gpu $N $LEAN 2>/dev/null | line impl sweep_impl.txt; done; done
+for N in 32768 49152 65536; do for I in split3 split jump; do python bench.py --impl $I --steps 480 --warmup 96 --lanes-per-gpu $N $LEAN 2>/dev/null | line impl sweep_impl.txt; done; done
+exit 0
+fi
+cd /tmp && export TMPDIR=/tmp
+B="$R/bench.py $LEAN --steps 960 --warmup 96"
+B20="$R/bench.py $LEAN --steps 20 --warmup 5"
+M="$R/bench.py --no-cpu-baseline --workload mpc --steps 20 --warmup 3"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_env -- python3 $B > $O/stats_env.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_env_f20 -- python3 $B20 > $O/stats_env_f20.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mpc -- python3 $M > $O/stats_mpc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_env_mpc -- python3 $R/bench.py --no-cpu-baseline --workload env_mpc --steps 48 --warmup 8 > $O/stats_env_mpc.log 2>&1
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_env -- python3 $B > $O/fetch_env.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_env -- python3 $B > $O/write_env.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_env_f20 -- python3 $B20 > $O/fetch_env_f20.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_env_f20 -- python3 $B20 > $O/write_env_f20.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_mpc -- python3 $M > $O/fetch_mpc.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_mpc -- python3 $M > $O/write_mpc.log 2>&1
+echo "traffic done"
+for tag in env env_f20; do
+  if [ $tag = env ]; then BB="$B"; else BB="$B20"; fi
+  i=0
+  for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
+             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
+             "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT"; do
+    i=$((i+1))
+    rocprofv3 --pmc $grp --output-format csv -d $O/sq_${tag}_g$i -- python3 $BB > $O/sq_${tag}_g$i.log 2>&1 || echo "SQ group $tag $i failed"
+  done
+done
+echo "sq done"
+cd $R
+KERNEL=mpc_select bash tools/gpu_sq_util.sh gpurun_out/$TAG/sq_util_mpc --workload mpc > $O/mpc_sq_counters.txt 2>&1 || true
+python tools/collect_profiles.py --stage $O

@@ -44,7 +44,7 @@ def measure(env, out, label):
         x = (w[:, 4] >> np.uint64(16)).astype(np.int64)
         res.append([rt[x == q].mean() for q in range(8)] + [rt.max()])
     r = np.array(res)[1:].mean(0)
-    print(f"{label:58s}" + " ".join(f"{v:6.1f}" for v in r[:8]) + f"   max {r[8]:6.1f}   ws {env.workspace.data_ptr():#x} obs {out['obs'].data_ptr():#x}")
+    print(f"{label:58s}" + " ".join(f"{v:6.1f}" for v in r[:8]) + f"   max {r[8]:6.1f}   ws {env.workspace.data_ptr():#x} obs {out['obs'].data_ptr() if out.get('obs') is not None else 0:#x}")
 
 
 print(" " * 58 + " ".join(f"  xcd{q}" for q in range(8)))
@@ -62,3 +62,6 @@ dummy2 = torch.empty(123 * 1024 * 1024 + 8192, dtype=torch.uint8, device="cuda")
 e3 = make(); o4 = outs()
 measure(e3, o4, "env 3 (after another dummy)")
 measure(e1, o1, "env 1, outputs 1 once more")
+measure(e1, dict(obs=None, reward=None, done=None, actions=None), "env 1, NO outputs at all (nothing but the lane state is written)")
+measure(e1, dict(obs=None, reward=o1["reward"], done=o1["done"], actions=None), "env 1, reward + done only (no observations)")
+measure(e1, o1, "env 1, outputs 1 at the end")
