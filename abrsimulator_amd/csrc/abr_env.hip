@@ -119,9 +119,8 @@ struct EnvParams {
     double *bw_hist;               // [V][n_lanes]
     double *ep_qoe_terms;          // [4][n_lanes]: rebuffer, startup, avg latency, bitrate variance of the last finished episode
     double *var_run;               // [n_lanes] sum of |br[a_i] - br[a_(i+1)]| over the running episode so far (:82), in its order
-    // abr_debug_selfcheck only (nullptr otherwise): a role-split kernel launched with this set writes 1 here if fresh_params()
-    // -- the parameter block re-read from the kernarg segment -- is THIS launch's block (it carries `sentinel`), 2 if not,
-    // and returns at once
+    // abr_debug_selfcheck only (nullptr otherwise): instance <9> of a role-split kernel writes 1 here if fresh_params() -- the
+    // parameter block re-read from the kernarg segment -- is THIS launch's block (it carries `sentinel`), 2 if not
     uint32_t *selfcheck_out;
     uint64_t sentinel;
 };
@@ -2106,21 +2105,19 @@ extern "C" int abr_debug_chain(int32_t stop_kind, int32_t estimate_bias, const d
 
 // Diagnostic: the contract the role-split kernels' fresh_params() rests on -- `EnvParams p` is the FIRST by-value kernel
 // argument, so the block at offset 0 of the kernarg segment is this launch's parameter block -- checked in the PRODUCT build:
-// every instance of both kernels is launched once (one workgroup) with a sentinel in its parameter block and answers whether
-// fresh_params() saw it.  result_dev: uint32 [6] device memory, entry i = 1 (seen) or 2 (not) for
-// env_split3_kernel<1,2,3>, env_split_kernel<1,2,3>.  Touches no lane state.
+// instance <9> of each of the two kernel templates (the product instances' signature, a body that only answers) is launched
+// once (one workgroup) with a sentinel in its parameter block and says whether fresh_params() saw it.  result_dev: uint32 [2]
+// device memory, entry 0 = env_split3_kernel, 1 = env_split_kernel: 1 (seen) or 2 (not).  Touches no lane state.
 extern "C" int abr_debug_selfcheck(abr_env *env, uint32_t *result_dev, void *stream) {
     if (!env || !result_dev) return fail(ABR_E_INVALID, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(result_dev, 0, 6 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(result_dev, 0, 2 * sizeof(uint32_t), st));
     EnvParams p = env->p;
     p.sentinel = 0x5eed0000c0ffee00ull ^ (uint64_t)(uintptr_t)env;
-#define ABR_SC(k, slot)                                                                                          \
-    p.selfcheck_out = result_dev + (slot);                                                                          \
-    hipLaunchKernelGGL(k, dim3(1), dim3((slot) < 3 ? 192 : 128), 0, st, p, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0ull);
-    ABR_SC(env_split3_kernel<1>, 0) ABR_SC(env_split3_kernel<2>, 1) ABR_SC(env_split3_kernel<3>, 2)
-    ABR_SC(env_split_kernel<1>, 3) ABR_SC(env_split_kernel<2>, 4) ABR_SC(env_split_kernel<3>, 5)
-#undef ABR_SC
+    p.selfcheck_out = result_dev;
+    hipLaunchKernelGGL(env_split3_kernel<9>, dim3(1), dim3(192), 0, st, p, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0ull);
+    p.selfcheck_out = result_dev + 1;
+    hipLaunchKernelGGL(env_split_kernel<9>, dim3(1), dim3(128), 0, st, p, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0ull);
     HIP_TRY(hipGetLastError());
     return ABR_OK;
 }

@@ -97,9 +97,11 @@ __device__ __forceinline__ void lds_writes_done() {
 // pointers and constants -- would be live across the whole loop and spill; re-reading the block behind a compiler-only
 // fence keeps each role's scalar loads inside that role's part of the iteration (a dozen s_load per iteration).
 // CONTRACT: `EnvParams p` must stay the FIRST by-value argument of env_split3_kernel and env_split_kernel (the block is read
-// from offset 0 of the kernarg segment).  The PRODUCT build can be asked: abr_debug_selfcheck launches every instance of both
-// kernels with a sentinel in the block and each answers whether fresh_params() saw it (tests/test_env_gpu.py); the diagnostic
-// stamps build also traps on a mismatch in every launch.
+// from offset 0 of the kernarg segment).  The PRODUCT build can be asked: abr_debug_selfcheck launches instance <9> of both
+// kernel templates -- the same signature, a body that only answers -- with a sentinel in the block, and each says whether
+// fresh_params() saw it (tests/test_env_gpu.py); the diagnostic stamps build also traps on a mismatch in every launch.
+// (A run-time branch on a field of the block at the top of the product instances cost the three-wave kernel 36 B of private
+// segment: one more live scalar than it has registers for.)
 __device__ __forceinline__ const EnvParams &fresh_params() {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __shared__ ActRing ring;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
-    if (p.selfcheck_out) { selfcheck_answer(p); return; }                            // abr_debug_selfcheck: every thread returns, before any barrier
+    if constexpr (MODE == 9) { selfcheck_answer(p); return; }                        // abr_debug_selfcheck's instance: nothing but the answer
 #ifdef ABR_SPLIT_STAMPS
     if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
 #endif
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(128) void env_split_kernel(
     __shared__ SplitMail m;
     const int32_t n_total = (MODE >= 2) ? n_steps : 1;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform by construction
-    if (p.selfcheck_out) { selfcheck_answer(p); return; }                            // abr_debug_selfcheck: every thread returns, before any barrier
+    if constexpr (MODE == 9) { selfcheck_answer(p); return; }                        // abr_debug_selfcheck's instance: nothing but the answer
 #ifdef ABR_SPLIT_STAMPS
     if (fresh_params().n_lanes != p.n_lanes || fresh_params().traces != p.traces) __builtin_trap();   // fresh_params' contract
 #endif

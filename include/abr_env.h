@@ -427,9 +427,10 @@ int abr_debug_drain(double sd, double max_level, const double *x0_dev, const int
 
 /* Diagnostic: a self-check of the PRODUCT build's role-split kernels (impl 2 and 5).  Their service code re-reads the launch's
  * parameter block from the kernel-argument segment every iteration instead of holding it in registers, which is only right
- * while that block is the kernels' first argument; every instance of both kernels is launched once (one workgroup, no lane
- * state touched) with a sentinel in the block and reports whether the re-read saw it.  result_dev: uint32 [6] device memory,
- * 1 = seen, 2 = not seen, 0 = that launch never ran. */
+ * while that block is the kernels' first argument; a checking instance of each of the two kernel templates (the product
+ * instances' signature) is launched once (one workgroup, no lane state touched) with a sentinel in the block and reports
+ * whether the re-read saw it.  result_dev: uint32 [2] device memory (three-wave kernel, two-wave kernel): 1 = seen,
+ * 2 = not seen, 0 = that launch never ran. */
 int abr_debug_selfcheck(abr_env *env, uint32_t *result_dev, void *stream);
 
 #ifdef __cplusplus

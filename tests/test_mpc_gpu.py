@@ -83,7 +83,9 @@ def test_sweeps_match_reference_goldens(name):
 
 
 @pytest.mark.parametrize("B,H,N", [(6, 5, 4096), (4, 5, 1000), (6, 3, 513), (3, 2, 100), (5, 4, 300),
-                                   (2, 8, 64), (16, 2, 50), (7, 6, 40), (16, 3, 20), (12, 4, 12), (4, 6, 200), (6, 6, 50), (6, 2, 300)])
+                                   (2, 8, 64), (16, 2, 50), (7, 6, 40), (16, 3, 20), (12, 4, 12), (4, 6, 200), (6, 6, 50), (6, 2, 300),
+                                   # the compile-time ladders of 8 rates (<H, 8, 0> for H <= 6) and 3 / 5 / 7 at other horizons
+                                   (8, 4, 100), (8, 3, 64), (8, 5, 24), (8, 6, 6), (3, 4, 200), (5, 5, 120), (7, 4, 60), (5, 3, 200)])
 def test_select_matches_oracle_seeded(oracle, B, H, N):
     rng = np.random.default_rng(B * 100 + H)
     V, L, mb = 40, 4.0, 20.0
